@@ -1,0 +1,233 @@
+/*
+ * vermilion_hip.h — C ABI of the MI355X (gfx950) path-tracing hot path.
+ *
+ * This is the drop-in boundary for Vermilion's `Integrator::Render` seam
+ * (reference: core/integrators/integrators.h:11-16, installed through
+ * RenderEngine::assignIntegrator, core/engines/renderEngine.cpp:70-78, and
+ * called from RenderEngine::draw, core/engines/renderEngine.cpp:163-164).
+ * A `HipPathTracer : Vermilion::Integrator` adapter flattens
+ * MeshEngine::sceneMeshes in createBVH order (core/engines/meshEngine.cpp:660-718)
+ * into plain float arrays and calls the functions below; everything else
+ * (Assimp import, OIIO texture read / image write, logging) stays on the host.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types cross this boundary
+ *   - every function returns an int status (VMX_OK == 0); the message for the
+ *     last failure on the calling thread is vmx_last_error()
+ *   - nothing throws across the ABI; the library never falls back to a CPU
+ *     path: without a usable HIP device every compute entry point fails with
+ *     VMX_ERR_NO_DEVICE
+ *   - synchronous and blocking unless a stream is passed explicitly
+ *     (reference Render is one synchronous call, renderEngine.cpp:163-164)
+ */
+#ifndef VERMILION_HIP_H
+#define VERMILION_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMX_ABI_VERSION 1
+
+/* status codes */
+#define VMX_OK 0
+#define VMX_ERR_INVALID 1     /* bad argument (NULL, zero size, NaN geometry ...)  */
+#define VMX_ERR_NO_DEVICE 2   /* no HIP device / device ordinal out of range        */
+#define VMX_ERR_HIP 3         /* a hip* call failed; text in vmx_last_error()       */
+#define VMX_ERR_DEPTH 4       /* BVH deeper than the reference's 64-entry traversal
+                                 stack (core/accelerators/bvh.cpp:54)               */
+#define VMX_ERR_NOMEM 5
+
+/* sphere flags */
+#define VMX_SPHERE_EMIT 1u /* hit writes `colour` into hitColour (meshEngine.cpp:382-383,415-416) */
+
+/* sampling modes (vmx_opts.sampling) */
+#define VMX_SAMPLING_PARITY 0u    /* r2 = 10*U, reference-faithful (pathtracer.cpp:156,170) */
+#define VMX_SAMPLING_CORRECTED 1u /* r2 = U, an actual cosine-weighted lobe; not a parity mode */
+
+/*
+ * One analytic sphere of MeshEngine::RayCast's hard-coded table
+ * (core/engines/meshEngine.cpp:377-500).  Spheres are tested after the BVH,
+ * in table order, each with `testHit > 0 && testHit < nearestHit`
+ * (meshEngine.cpp:378); a nearer sphere overwrites the hit normal with
+ *   normal_sign * normalize(hit - normal_centre)
+ * and, if VMX_SPHERE_EMIT is set, overwrites hitColour with `colour`.
+ * hitColour is never cleared by a later, nearer sphere (quirk kept on purpose).
+ */
+typedef struct vmx_sphere {
+    float centre[3];
+    float radius;
+    float colour[3];
+    uint32_t flags;
+    float normal_centre[3];
+    float normal_sign; /* +1 or -1 */
+} vmx_sphere;
+
+/*
+ * Camera parameters = Vermilion::cameraSettings (core/camera/camera.h:32-47)
+ * restricted to the fields PathTracer::Render reads.  The library applies the
+ * Camera constructor's conversion (core/camera/camera.cpp:43-47):
+ *   mRotation = (-rx, -ry, +rz) * 3.1415926535 / 180.
+ */
+typedef struct vmx_camera {
+    float position[3];     /* cameraSettings.position                        */
+    float rotation_deg[3]; /* cameraSettings.rotation (degrees)              */
+    float back_distance;   /* cameraSettings.fBackDistance -> mDistToFilm    */
+    float back_size[2];    /* cameraSettings.fBackSizeX/Y  -> sensorSizeX/Y  */
+    uint32_t image_res[2]; /* imageResX, imageResY                           */
+    uint32_t rays_per_pixel; /* raysPerPixel -> uSamplesPerPixel             */
+} vmx_camera;
+
+typedef struct vmx_opts {
+    uint64_t seed;         /* the reference seeds from std::random_device (pathtracer.cpp:231);
+                              here the stream of sample k of pixel p is keyed by (seed, p, k) */
+    uint32_t early_stop;   /* 1: reference early-stop rule (pathtracer.cpp:290-311); 0: fixed spp */
+    uint32_t sampling;     /* VMX_SAMPLING_*                                  */
+    uint32_t rank;         /* image-stripe sharding: this call renders the stripes s   */
+    uint32_t world;        /*   with s % world == rank; world 0 or 1 = whole image     */
+    uint32_t stripe_rows;  /* rows per stripe; 0 -> 16                         */
+    uint32_t samples_per_batch; /* fixed-spp mode: samples per pixel in flight per pass; 0 -> auto */
+    uint32_t collect_counters;  /* 1: also count inner-node visits / triangle tests
+                                   (instrumented kernels, slower; for roofline accounting) */
+    uint32_t reserved[7];
+} vmx_opts;
+
+/* per-stage figures: `primary` = Radiance steps taken at depth 0 (the fused
+ * raygen + trace + shade kernel), `bounce` = every later step */
+typedef struct vmx_stage_stats {
+    uint64_t rays;          /* RayCast-equivalents with a finite direction            */
+    uint64_t inner_visits;  /* inner-node visits (both child boxes tested); 0 unless collect_counters */
+    uint64_t tri_tests;     /* Moller-Trumbore tests; 0 unless collect_counters       */
+    uint64_t tri_hits;      /* rays whose BVH query hit a triangle                    */
+    uint64_t continued;     /* path states written across a bounce boundary           */
+    uint64_t launches;      /* kernel launches of this stage                          */
+    double ms;              /* sum of hipEvent durations of those launches            */
+} vmx_stage_stats;
+
+typedef struct vmx_stats {
+    uint64_t rays_primary;      /* = primary.rays                                      */
+    uint64_t rays_secondary;    /* = bounce.rays (NaN directions are not rays)         */
+    uint64_t samples;           /* pixel samples accumulated into the image            */
+    uint64_t samples_discarded; /* speculative samples traced but dropped by early stop */
+    uint64_t passes;            /* sample batches processed                            */
+    uint64_t kernel_launches;
+    double ms_total;            /* wall time of the call, host clock                   */
+    double ms_device;           /* hipEvent time of the device work on the render stream */
+    vmx_stage_stats primary;
+    vmx_stage_stats bounce;
+} vmx_stats;
+
+typedef struct vmx_scene_desc {
+    uint32_t ntris;
+    uint32_t nspheres;
+    uint32_t leaf_size;
+    uint32_t n_nodes;      /* reference flat-tree node count (bvh.cpp:203)   */
+    uint32_t n_leaves;     /* bvh.cpp:221                                    */
+    uint32_t n_inner;      /* 2-wide records on the device                   */
+    uint32_t max_depth;    /* root = 0                                       */
+    uint32_t stack_entries;/* per-lane LDS stack entries the kernels use     */
+    uint64_t device_bytes; /* HBM held by the scene                          */
+    int32_t device;
+    uint32_t pad;
+} vmx_scene_desc;
+
+/* full output tuple of MeshEngine::RayCast (meshEngine.cpp:239-509) for one ray */
+typedef struct vmx_rayhit {
+    float location[3]; /* pHitLocation                                         */
+    float distance;    /* pHitDistance (INFINITY on a miss)                    */
+    float normal[3];   /* pHitNormal                                           */
+    int32_t tri_id;    /* createBVH push-order index of the BVH hit, -1 if none */
+    float uv[2];       /* pHitTexCoord                                         */
+    float tri_t;       /* BVH t (999999999.f if none), bvh.cpp:48              */
+    uint32_t flags;    /* bit0: return value (nearest < INF); bit1: material non-null */
+    float colour[3];   /* pHitColour                                           */
+    uint32_t pad;
+} vmx_rayhit;
+
+typedef struct vmx_scene vmx_scene;
+
+/* ---- library ---------------------------------------------------------- */
+int vmx_abi_version(void);
+const char *vmx_last_error(void);
+/* number of HIP devices visible to the library (0 if none / runtime missing) */
+int vmx_device_count(void);
+
+/* The reference's eight spheres (meshEngine.cpp:377-500): 2 lights + 6 walls. */
+const vmx_sphere *vmx_default_spheres(uint32_t *count);
+
+/* ---- scene ------------------------------------------------------------ */
+/*
+ * Replaces MeshEngine::createBVH + BVH::BVH/build (meshEngine.cpp:649-724,
+ * bvh.cpp:155-279) for the device: `pos`/`nrm` are [ntris*9] floats
+ * (v0,v1,v2 / n0,n1,n2 per triangle), `uv` is [ntris*6] or NULL (zeros),
+ * in createBVH push order — that order defines triangle IDs.
+ * spheres == NULL && nspheres == 0 selects vmx_default_spheres().
+ * leaf_size 0 -> 4 (bvh.h:29).  The BVH is built on the host with the
+ * reference's topology, flattened to 2-wide records and uploaded to `device`.
+ */
+int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
+                     const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size,
+                     int device, vmx_scene **out);
+int vmx_scene_destroy(vmx_scene *scene);
+int vmx_scene_describe(const vmx_scene *scene, vmx_scene_desc *out);
+/*
+ * Host-side BVH topology in the reference's flat layout (bvh.h:11-14): per
+ * node start, nPrims, rightOffset ([n_nodes] each, any may be NULL), bbox
+ * [n_nodes*6] (min,max) and the final build_prims permutation [ntris].
+ */
+int vmx_scene_bvh(const vmx_scene *scene, uint32_t *start, uint32_t *nprims,
+                  uint32_t *right_offset, float *bbox, uint32_t *prim_order);
+
+/* ---- parity hooks (explicit ray batches, host buffers) ----------------- */
+/* BVH::getIntersection (bvh.cpp:47-145): tri_id[n] (-1 = miss), t[n] */
+int vmx_trace(const vmx_scene *scene, const float *origin, const float *dir, uint32_t n,
+              int32_t *tri_id, float *t);
+/* MeshEngine::RayCast (meshEngine.cpp:239-509) */
+int vmx_raycast(const vmx_scene *scene, const float *origin, const float *dir, uint32_t n,
+                vmx_rayhit *out);
+/*
+ * Primary-hit AOV: generates sample k's camera ray of every pixel on the
+ * device (pathtracer.cpp:251-280) and returns BVH::getIntersection's result,
+ * tri_id[W*H] / t[W*H] in pixel order (the "primary-hit triangle ID" map).
+ */
+int vmx_primary_ids(const vmx_scene *scene, const vmx_camera *cam, const vmx_opts *opts, uint32_t k,
+                    int32_t *tri_id, float *t);
+/*
+ * Radiance (pathtracer.cpp:21-198) for n explicit camera rays; ray i draws
+ * from the stream keyed (opts->seed, i, 0) with the two pixel-jitter draws
+ * skipped.  out[n*4] = accumColour (rgb, w = primary hit distance or -100).
+ */
+int vmx_radiance(const vmx_scene *scene, const float *origin, const float *dir, uint32_t n,
+                 const vmx_opts *opts, float *out, vmx_stats *stats);
+
+/* ---- render (replaces PathTracer::Render, pathtracer.cpp:200-328) ------ */
+/* number of image rows / pixels this (rank, world) owns */
+int vmx_local_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world,
+                   uint32_t *rows);
+/*
+ * Render into a caller-owned HOST buffer.  world <= 1: out is W*H*5 floats in
+ * Camera::mImage RGBAZ layout (camera.cpp:106-113): r,g,b in [0,1], alpha 1,
+ * depth = samples taken (pathtracer.cpp:318-323).  world > 1: out holds only
+ * this rank's rows, packed in ascending row order (local_rows*W*5 floats).
+ */
+int vmx_render(const vmx_scene *scene, const vmx_camera *cam, const vmx_opts *opts,
+               float *out_rgbaz, vmx_stats *stats);
+/* Same, but `d_out` is DEVICE memory on the scene's device and the work is
+ * enqueued on `stream` (a hipStream_t; NULL = the library's own stream).
+ * Blocks until the frame is complete (the early-stop loop needs the host). */
+int vmx_render_device(const vmx_scene *scene, const vmx_camera *cam, const vmx_opts *opts,
+                      void *d_out_rgbaz, void *stream, vmx_stats *stats);
+/*
+ * Multi-GPU assembly on the root: `d_gathered` = world packed per-rank buffers
+ * back to back, each padded to `rank_stride_floats`; writes the W*H*5 frame.
+ */
+int vmx_assemble_device(const void *d_gathered, uint64_t rank_stride_floats, uint32_t width,
+                        uint32_t height, uint32_t stripe_rows, uint32_t world, void *d_frame,
+                        int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VERMILION_HIP_H */

@@ -1,0 +1,897 @@
+/*
+ * vmx_oracle.cpp — CPU ORACLE for the Vermilion path-tracing hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under vermilion_amd/ or in
+ * libvermilion_hip.so may include, link, import or execute this file; it is
+ * loaded only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg, and there only as the checker / the timed CPU baseline.
+ *
+ * What it is: an independent restatement, in plain C++ with its own small
+ * vector types, of the reference's algorithm for
+ *   BBox::intersect                 core/accelerators/bbox.cpp:70-83
+ *   Triangle::getIntersection       core/accelerators/triangle.cpp:4-54
+ *   Triangle::getNormal             core/accelerators/triangle.cpp:56-87
+ *   BVH::build / getIntersection    core/accelerators/bvh.cpp:179-279 / 47-145
+ *   sphereIntersect                 core/engines/meshEngine.cpp:182-194
+ *   MeshEngine::RayCast             core/engines/meshEngine.cpp:239-509
+ *   Radiance                        core/integrators/pathtracer.cpp:21-198
+ *   PathTracer::Render              core/integrators/pathtracer.cpp:200-328
+ *   Camera ctor / setPixelValue     core/camera/camera.cpp:34-81, 88-124
+ * Each function below cites the lines it follows.
+ *
+ * PARITY UNPINNED.  The reference ships no tests, golden vectors or fixtures
+ * (SURVEY.md §4), and its hot path cannot be compiled in this image: every
+ * translation unit needs GLM (extern/glm is an empty, un-pinned submodule,
+ * .gitmodules:7-9) and meshEngine/camera additionally need Assimp and
+ * OpenImageIO headers; building it would need hand-written stand-ins for
+ * those headers, which is not a reference build.  GLM's arithmetic is
+ * therefore restated from its published generic (non-SIMD) code path
+ * (0.9.9 series: dot = (x*x + y*y) + z*z, normalize = v * (1/sqrt(dot)),
+ * cross, mat4*vec4 as (m0*x + m1*y) + (m2*z + m3*w), gtc rotate); libstdc++'s
+ * <random> is used directly where the reference's RNG is wanted.  The only
+ * reference-run observations available are the probe results recorded in
+ * SURVEY.md (Appendix A-1/A-2/A-9, §8a-6); tests/test_oracle_quirks.py checks
+ * this file against those.
+ *
+ * Build: see oracle/Makefile.  The parity build is -O2 -ffp-contract=off
+ * (every float operation rounds once, no FMA), which is what the HIP kernels
+ * are compiled to match.
+ */
+#include "vmx_oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+/* ------------------------------------------------------------------ */
+/* vector arithmetic (GLM generic path, restated)                      */
+/* ------------------------------------------------------------------ */
+struct V2 {
+    float x, y;
+};
+struct V3 {
+    float x, y, z;
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+struct V4 {
+    float x, y, z, w;
+};
+
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator/(V3 a, V3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline V2 operator*(V2 a, float s) { return {a.x * s, a.y * s}; }
+inline V2 operator+(V2 a, V2 b) { return {a.x + b.x, a.y + b.y}; }
+inline V4 operator+(V4 a, V4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline V4 operator*(V4 a, V4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+
+/* glm::dot(vec3): tmp = a*b; tmp.x + tmp.y + tmp.z */
+inline float dot(V3 a, V3 b) {
+    V3 t = a * b;
+    return t.x + t.y + t.z;
+}
+/* glm::cross */
+inline V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+/* glm::length = sqrt(dot(v,v)) */
+inline float length(V3 v) { return std::sqrt(dot(v, v)); }
+/* glm::normalize = v * inversesqrt(dot(v,v)), inversesqrt(x) = 1/sqrt(x) */
+inline V3 normalize(V3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
+/* glm::min / glm::max: (b<a)?b:a and (a<b)?b:a per component */
+inline float gmin(float a, float b) { return (b < a) ? b : a; }
+inline float gmax(float a, float b) { return (a < b) ? b : a; }
+
+/* ------------------------------------------------------------------ */
+/* scene                                                               */
+/* ------------------------------------------------------------------ */
+struct Tri { /* core/accelerators/triangle.h:5-9 */
+    V3 v0, v1, v2;
+    V3 n0, n1, n2;
+    V2 t0, t1, t2;
+    uint32_t id; /* createBVH push order, meshEngine.cpp:712 */
+};
+
+struct Box { /* core/accelerators/bbox.h:6-7 */
+    V3 lo, hi, extent;
+};
+
+inline Box box_of(V3 lo, V3 hi) { return Box{lo, hi, hi - lo}; } /* bbox.cpp:5-6 */
+inline Box box_of(V3 p) { return Box{p, p, p - p}; }             /* bbox.cpp:8-9 */
+inline void grow(Box &b, V3 p) {                                 /* bbox.cpp:29-33 */
+    b.lo = {std::min(b.lo.x, p.x), std::min(b.lo.y, p.y), std::min(b.lo.z, p.z)};
+    b.hi = {std::max(b.hi.x, p.x), std::max(b.hi.y, p.y), std::max(b.hi.z, p.z)};
+    b.extent = b.hi - b.lo;
+}
+inline void grow(Box &b, const Box &o) { /* bbox.cpp:35-39 */
+    b.lo = {std::min(b.lo.x, o.lo.x), std::min(b.lo.y, o.lo.y), std::min(b.lo.z, o.lo.z)};
+    b.hi = {std::max(b.hi.x, o.hi.x), std::max(b.hi.y, o.hi.y), std::max(b.hi.z, o.hi.z)};
+    b.extent = b.hi - b.lo;
+}
+/* bbox.cpp:41-46 — note: z is compared with y only */
+inline uint32_t widest_axis(const Box &b) {
+    uint32_t r = 0;
+    if (b.extent.y > b.extent.x) r = 1;
+    if (b.extent.z > b.extent.y) r = 2;
+    return r;
+}
+/* triangle.cpp:107-114 */
+inline Box tri_box(const Tri &t) {
+    V3 lo = {std::min(std::min(t.v0.x, t.v1.x), t.v2.x), std::min(std::min(t.v0.y, t.v1.y), t.v2.y),
+             std::min(std::min(t.v0.z, t.v1.z), t.v2.z)};
+    V3 hi = {std::max(std::max(t.v0.x, t.v1.x), t.v2.x), std::max(std::max(t.v0.y, t.v1.y), t.v2.y),
+             std::max(std::max(t.v0.z, t.v1.z), t.v2.z)};
+    return box_of(lo, hi);
+}
+/* triangle.cpp:116-119 */
+inline V3 tri_centroid(const Tri &t) { return (t.v0 + t.v1 + t.v2) * 0.333f; }
+
+struct FlatNode { /* bvh.h:11-14 */
+    Box box;
+    uint32_t start, nprims, right_offset;
+};
+
+struct RayQ { /* Ray.h:4-11 */
+    V3 o, d, inv_d;
+};
+inline RayQ make_ray(V3 o, V3 d) { return RayQ{o, d, v3(1, 1, 1) / d}; }
+
+struct Counters {
+    uint64_t inner_visits = 0, tri_tests = 0, pops = 0, max_stack = 0;
+};
+
+} // namespace
+
+struct orc_scene {
+    std::vector<Tri> tris;          /* storage, createBVH order */
+    std::vector<const Tri *> prims; /* build_prims, permuted by build (bvh.cpp:252) */
+    std::vector<FlatNode> nodes;
+    std::vector<vmx_sphere> spheres;
+    uint32_t leaf_size = 4, n_leaves = 0, max_depth = 0;
+};
+
+namespace {
+
+/* BVH::build, bvh.cpp:179-279 */
+void build_bvh(orc_scene &sc) {
+    struct Entry {
+        uint32_t parent, start, end, depth;
+    };
+    const uint32_t kRoot = 0xfffffffcu, kUntouched = 0xffffffffu, kTouchedTwice = 0xfffffffdu;
+    std::vector<Entry> todo;
+    todo.push_back({kRoot, 0, (uint32_t)sc.prims.size(), 0});
+    std::vector<FlatNode> &out = sc.nodes;
+    out.clear();
+    out.reserve(sc.prims.size() * 2);
+    uint32_t n_nodes = 0;
+    sc.n_leaves = 0;
+    sc.max_depth = 0;
+    while (!todo.empty()) {
+        Entry e = todo.back();
+        todo.pop_back();
+        uint32_t start = e.start, end = e.end, np = end - start;
+        n_nodes++;
+        FlatNode node;
+        node.start = start;
+        node.nprims = np;
+        node.right_offset = kUntouched;
+        Box bb = tri_box(*sc.prims[start]);           /* :209 */
+        Box bc = box_of(tri_centroid(*sc.prims[start])); /* :210 */
+        for (uint32_t p = start + 1; p < end; ++p) {
+            grow(bb, tri_box(*sc.prims[p]));
+            grow(bc, tri_centroid(*sc.prims[p]));
+        }
+        node.box = bb;
+        if (np <= sc.leaf_size) { /* :219 */
+            node.right_offset = 0;
+            sc.n_leaves++;
+        }
+        out.push_back(node);
+        sc.max_depth = std::max(sc.max_depth, e.depth);
+        if (e.parent != kRoot) { /* :228-236 */
+            out[e.parent].right_offset--;
+            if (out[e.parent].right_offset == kTouchedTwice)
+                out[e.parent].right_offset = n_nodes - 1 - e.parent;
+        }
+        if (node.right_offset == 0) continue;
+        uint32_t dim = widest_axis(bc);                            /* :243 */
+        float split = .5f * (bc.lo[dim] + bc.hi[dim]);             /* :246 */
+        uint32_t mid = start;
+        for (uint32_t i = start; i < end; ++i) {                   /* :250-255 */
+            if (tri_centroid(*sc.prims[i])[dim] < split) {
+                std::swap(sc.prims[i], sc.prims[mid]);
+                ++mid;
+            }
+        }
+        if (mid == start || mid == end) mid = start + (end - start) / 2; /* :258-260 */
+        todo.push_back({n_nodes - 1, mid, end, e.depth + 1});   /* right first, :263-266 */
+        todo.push_back({n_nodes - 1, start, mid, e.depth + 1}); /* left on top, :269-272 */
+    }
+}
+
+/* BBox::intersect, bbox.cpp:70-83 */
+inline bool box_hit(const Box &b, const RayQ &r, float *tnear, float *tfar) {
+    V3 t0 = (b.lo - r.o) * r.inv_d;
+    V3 t1 = (b.hi - r.o) * r.inv_d;
+    V3 ts = {gmin(t0.x, t1.x), gmin(t0.y, t1.y), gmin(t0.z, t1.z)};
+    V3 tl = {gmax(t0.x, t1.x), gmax(t0.y, t1.y), gmax(t0.z, t1.z)};
+    *tnear = std::max(std::max(ts.x, ts.y), ts.z);
+    *tfar = std::min(std::min(tl.x, tl.y), tl.z);
+    return *tnear <= *tfar;
+}
+
+/* Triangle::getIntersection, triangle.cpp:4-54 */
+inline bool tri_hit(const Tri &tr, const RayQ &ray, float *t_out) {
+    V3 rot = ray.d, pos = ray.o;
+    V3 e1 = tr.v1 - tr.v0;
+    V3 e2 = tr.v2 - tr.v0;
+    V3 pvec = cross(rot, e2);
+    float det = dot(e1, pvec);
+    if (det < 1e-8 && det > -1e-8) return false; /* double literals, :25 */
+    float inv_det = 1 / det;
+    V3 tvec = pos - tr.v0;
+    float u = dot(tvec, pvec) * inv_det;
+    if (u < 0 || u > 1) return false;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(rot, qvec) * inv_det;
+    if (v < 0 || u + v > 1) return false;
+    float dist = dot(e2, qvec) * inv_det;
+    if (dist > 0.0f) {
+        *t_out = dist;
+        return true;
+    }
+    return false;
+}
+
+/* Triangle::getNormal, triangle.cpp:56-87 (lines 58-65 are dead code: their
+ * results are overwritten before use) */
+inline V3 tri_normal(const Tri &tr, V3 hit, V2 *uv) {
+    V3 f0 = tr.v1 - tr.v0;
+    V3 f1 = tr.v2 - tr.v0;
+    V3 f2 = hit - tr.v0;
+    float d00 = dot(f0, f0);
+    float d01 = dot(f0, f1);
+    float d11 = dot(f1, f1);
+    float d20 = dot(f2, f0);
+    float d21 = dot(f2, f1);
+    float denom = d00 * d11 - d01 * d01;
+    float w1 = (d11 * d20 - d01 * d21) / denom;
+    float w2 = (d00 * d21 - d01 * d20) / denom;
+    float w0 = 1 - w1 - w2;
+    V3 n = tr.n0 * w0 + tr.n1 * w1 + tr.n2 * w2;
+    if (uv) *uv = tr.t0 * w0 + tr.t1 * w1 + tr.t2 * w2;
+    return -n;
+}
+
+/* BVH::getIntersection (occlusion == false), bvh.cpp:47-145 */
+inline bool bvh_nearest(const orc_scene &sc, const RayQ &ray, float *t_out, const Tri **obj_out,
+                        Counters *cnt) {
+    float best = 999999999.f;
+    const Tri *obj = nullptr;
+    struct Todo {
+        uint32_t i;
+        float mint;
+    } todo[64];
+    int sp = 0;
+    todo[0] = {0, -9999999.f};
+    float bb[4] = {0, 0, 0, 0};
+    while (sp >= 0) {
+        int ni = (int)todo[sp].i;
+        float near = todo[sp].mint;
+        sp--;
+        if (cnt) cnt->pops++;
+        const FlatNode &node = sc.nodes[ni];
+        if (near > best) continue; /* :69 */
+        if (node.right_offset == 0) {
+            for (uint32_t o = 0; o < node.nprims; ++o) {
+                const Tri *tr = sc.prims[node.start + o];
+                float tt;
+                if (cnt) cnt->tri_tests++;
+                if (tri_hit(*tr, ray, &tt)) {
+                    if (tt < best) { /* strict: first tested wins ties, :90 */
+                        best = tt;
+                        obj = tr;
+                    }
+                }
+            }
+        } else {
+            if (cnt) cnt->inner_visits++;
+            bool h0 = box_hit(sc.nodes[ni + 1].box, ray, bb, bb + 1);
+            bool h1 = box_hit(sc.nodes[ni + node.right_offset].box, ray, bb + 2, bb + 3);
+            if (h0 && h1) {
+                int closer = ni + 1, other = ni + (int)node.right_offset;
+                if (bb[2] < bb[0]) { /* :110 */
+                    std::swap(bb[0], bb[2]);
+                    std::swap(bb[1], bb[3]);
+                    std::swap(closer, other);
+                }
+                todo[++sp] = {(uint32_t)other, bb[2]};
+                todo[++sp] = {(uint32_t)closer, bb[0]};
+            } else if (h0) {
+                todo[++sp] = {(uint32_t)(ni + 1), bb[0]};
+            } else if (h1) {
+                todo[++sp] = {(uint32_t)(ni + node.right_offset), bb[2]};
+            }
+            if (cnt && (uint64_t)(sp + 1) > cnt->max_stack) cnt->max_stack = (uint64_t)(sp + 1);
+        }
+    }
+    *t_out = best;
+    *obj_out = obj;
+    return obj != nullptr;
+}
+
+/* sphereIntersect, meshEngine.cpp:182-194 — note the float dots and the
+ * float rad*rad feeding a double discriminant */
+inline float sphere_hit(V3 pos, V3 rot, V3 p, const float rad) {
+    V3 op = p - pos;
+    double t;
+    double eps = 1e-4;
+    double b = dot(op, rot);
+    double det = b * b - dot(op, op) + rad * rad;
+    if (det < 0)
+        return 0;
+    else
+        det = std::sqrt(det);
+    return (float)((t = b - det) > eps ? t : ((t = b + det) > eps ? t : 0));
+}
+
+const vmx_sphere kDefaultSpheres[8] = {
+    /* meshEngine.cpp:377-387  light 1 */
+    {{15.f, 140.f, 25.f}, 3.5f, {0.f * 15.f, .5f * 15.f, 1.0f * 15.f}, VMX_SPHERE_EMIT, {-55.f, 350.f, -150.f}, -1.f},
+    /* meshEngine.cpp:410-420  light 2 */
+    {{0.f, 3300.f, 1300.f}, 250.f, {1.0f * 15.2f, 1.0f * 15.2f, 1.0f * 15.2f}, VMX_SPHERE_EMIT, {500.f, 800.f, 1300.f}, 1.f},
+    /* meshEngine.cpp:444-450  floor */
+    {{0.f, (float)(-1e7 * 5), 0.f}, (float)(1e7 * 5), {0, 0, 0}, 0u, {0.f, (float)(-1e7 * 5), 0.f}, 1.f},
+    /* :452-459 ceiling */
+    {{0.f, (float)(1e7 * 5 + 1000), 0.f}, (float)(1e7 * 5), {0, 0, 0}, 0u, {0.f, (float)(1e7 * 5 + 1000), 0.f}, 1.f},
+    /* :463-470 -x wall */
+    {{(float)(-1e7 * 5 + 2000), 0.f, 0.f}, (float)(1e7 * 5), {0, 0, 0}, 0u, {(float)(-1e7 * 5 + 2000), 0.f, 0.f}, -1.f},
+    /* :472-479 +x wall */
+    {{(float)(1e7 * 5 - 2000), 0.f, 0.f}, (float)(1e7 * 5), {0, 0, 0}, 0u, {(float)(1e7 * 5 - 2000), 0.f, 0.f}, -1.f},
+    /* :483-490 -z wall */
+    {{0.f, 0.f, (float)(-1e7 * 5 + 2000)}, (float)(1e7 * 5), {0, 0, 0}, 0u, {0.f, 0.f, (float)(-1e7 * 5 + 2000)}, -1.f},
+    /* :492-499 +z wall */
+    {{0.f, 0.f, (float)(1e7 * 5 - 2000)}, (float)(1e7 * 5), {0, 0, 0}, 0u, {0.f, 0.f, (float)(1e7 * 5 - 2000)}, 1.f},
+};
+
+struct CastOut {
+    bool hit;      /* return value */
+    bool material; /* *ppImpactMaterial != nullptr */
+    V3 location, normal, colour;
+    V2 uv;
+    float distance;
+    int32_t tri_id;
+    float tri_t;
+};
+
+/* MeshEngine::RayCast, meshEngine.cpp:239-509 */
+inline CastOut ray_cast(const orc_scene &sc, V3 o, V3 d, Counters *cnt) {
+    CastOut r;
+    r.uv = {0, 0};
+    r.normal = {0, 0, 0};
+    r.colour = {0, 0, 0};
+    r.material = false;
+    r.location = {0, 0, 0};
+    r.distance = 0.f;
+    r.tri_id = -1;
+    float nearest = INFINITY; /* :271 */
+    float test = 0.f;
+    int hit_mesh = -1;
+
+    RayQ ray = make_ray(o, d); /* :361 */
+    float bt;
+    const Tri *obj;
+    bool bh = bvh_nearest(sc, ray, &bt, &obj, cnt); /* :364 */
+    r.tri_t = bt;
+    if (bh) {
+        nearest = bt;
+        V3 hitp = ray.o + ray.d * bt;                    /* bvh.cpp:140 */
+        r.normal = normalize(tri_normal(*obj, hitp, &r.uv)); /* :369 */
+        hit_mesh = 0;
+        r.tri_id = (int32_t)obj->id;
+    }
+    for (const vmx_sphere &s : sc.spheres) { /* :377-499, table order */
+        test = sphere_hit(o, d, v3(s.centre[0], s.centre[1], s.centre[2]), s.radius);
+        if (test > 0.f && test < nearest) {
+            nearest = test;
+            if (s.flags & VMX_SPHERE_EMIT) r.colour = v3(s.colour[0], s.colour[1], s.colour[2]);
+            V3 nc = v3(s.normal_centre[0], s.normal_centre[1], s.normal_centre[2]);
+            V3 n = normalize(o + (d * nearest) - nc);
+            r.normal = (s.normal_sign < 0.f) ? -n : n;
+        }
+    }
+    if (hit_mesh >= 0) r.material = true; /* :502-503 */
+    r.location = o + (d * nearest);       /* :505 */
+    r.distance = nearest;                 /* :507 */
+    r.hit = nearest < INFINITY;           /* :508 */
+    return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* RNG                                                                 */
+/* ------------------------------------------------------------------ */
+inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t splitmix64(uint64_t &x) {
+    x += 0x9E3779B97F4A7C15ull;
+    return mix64(x);
+}
+inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+/* keyed xoshiro256** stream: state = 4 splitmix64 outputs from
+ * x0 = mix64(seed ^ (pixel << 32 | k)).  (DESIGN.md "RNG") */
+struct Xoshiro {
+    uint64_t s0, s1, s2, s3;
+    void init(uint64_t seed, uint32_t pixel, uint32_t k) {
+        uint64_t x = mix64(seed ^ (((uint64_t)pixel << 32) | (uint64_t)k));
+        s0 = splitmix64(x);
+        s1 = splitmix64(x);
+        s2 = splitmix64(x);
+        s3 = splitmix64(x);
+    }
+    uint64_t next() {
+        uint64_t r = rotl64(s1 * 5, 7) * 9;
+        uint64_t t = s1 << 17;
+        s2 ^= s0;
+        s3 ^= s1;
+        s1 ^= s2;
+        s0 ^= s3;
+        s2 ^= t;
+        s3 = rotl64(s3, 45);
+        return r;
+    }
+    /* uniform double in [0,1): 52 mantissa bits */
+    double u01() {
+        uint64_t b = 0x3FF0000000000000ull | (next() >> 12);
+        double dd;
+        std::memcpy(&dd, &b, 8);
+        return dd - 1.0;
+    }
+    /* uniform_real_distribution<float>(0, 0.5) stand-in: 23 mantissa bits */
+    float jitter() {
+        uint32_t b = 0x3F800000u | (uint32_t)(next() >> 41);
+        float f;
+        std::memcpy(&f, &b, 4);
+        return (f - 1.0f) * 0.5f;
+    }
+};
+
+/* the reference's generator: std::mt19937_64 + std distributions, pathtracer.cpp:23,230-231 */
+struct MtRng {
+    std::mt19937_64 eng;
+    std::uniform_real_distribution<double> dd{0.0, 1.0};
+    std::uniform_real_distribution<float> df{0, 0.5};
+    bool seeded = false;
+    double u01() { return dd(eng); }
+    float jitter() { return df(eng); }
+};
+
+struct PathStats {
+    uint64_t rays_primary = 0, rays_secondary = 0, tri_hits = 0, continued = 0;
+    Counters cnt;
+};
+
+inline bool finite3(V3 v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); }
+
+/* Radiance, pathtracer.cpp:21-198.  No texture is bound in any configuration
+ * (pathtracer.cpp:63-66 not taken), so sampleColour is (1,1,1,1) (:75-79). */
+template <class Rng>
+V4 radiance(const orc_scene &sc, V3 rStart, V3 rDir, Rng &rng, uint32_t sampling, PathStats *st,
+            bool count_nodes) {
+    V4 accumColour = {0, 0, 0, -100};
+    V4 accumRadiance = {1, 1, 1, 1};
+    short depth = 0;
+    const double r2scale = (sampling == VMX_SAMPLING_CORRECTED) ? 1.0 : 10.0;
+    while (1) {
+        bool is_ray = finite3(rDir); /* NaN directions are not rays */
+        if (st) {
+            if (depth == 0)
+                st->rays_primary++;
+            else if (is_ray)
+                st->rays_secondary++;
+        }
+        CastOut c = ray_cast(sc, rStart, rDir, (st && count_nodes && is_ray) ? &st->cnt : nullptr);
+        if (!c.hit) return accumColour; /* :36-41 */
+        if (st && c.tri_id >= 0) st->tri_hits++;
+        accumColour = accumColour + accumRadiance * V4{c.colour.x, c.colour.y, c.colour.z, 0.f}; /* :43 */
+        if (depth == 0) accumColour.w = c.distance;                                            /* :44-47 */
+        if (length(c.colour) > 1.f) return accumColour;                                        /* :52 */
+        if (++depth > 5 && (rng.u01() > 0.95f || depth > 1000)) return accumColour;            /* :56-59 */
+        V4 sampleColour = {1.f, 1.f, 1.f, 1.0};                                                /* :75-79 */
+        V3 n = c.normal;
+        V3 next_dir;
+        if (c.material && rng.u01() >= 0.96) { /* :98-109 specular */
+            (void)rng.u01();
+            (void)rng.u01();
+            (void)rng.u01(); /* :101-103, unused noise */
+            rStart = c.location - rDir * 0.001f;
+            next_dir = normalize(rDir - n * 2.f * dot(n, rDir));
+        } else if (c.material) { /* :151-165 */
+            accumRadiance = accumRadiance * sampleColour;
+            float r1 = (float)(2 * M_PI * rng.u01());
+            float r2 = (float)(r2scale * rng.u01());
+            float r2s = std::sqrt(r2);
+            V3 w = dot(n, rDir) < 0.f ? n : n * -1.f;
+            V3 u = normalize(cross(std::fabs(w.x) > .1 ? v3(0, 1, 0) : v3(1, 0, 0), w));
+            V3 v = cross(w, u);
+            V3 dd = normalize(u * (float)std::cos((double)r1) * r2s + v * (float)std::sin((double)r1) * r2s +
+                              w * (float)std::sqrt(1 - r2));
+            rStart = c.location - rDir * 0.001f;
+            next_dir = dd;
+        } else { /* :166-196, nearest hit is a sphere and the BVH hit nothing */
+            double r1 = 2 * M_PI * rng.u01();
+            double r2 = r2scale * rng.u01();
+            float r2s = (float)std::sqrt(r2);
+            (void)rng.u01();
+            (void)rng.u01();
+            (void)rng.u01(); /* :173-175, unused noise */
+            V3 w = dot(n, rDir) < 0.f ? n : n * -1.f;
+            V3 u = normalize(cross(std::fabs(w.x) > .1 ? v3(0, 1, 0) : v3(1, 0, 0), w));
+            V3 v = cross(w, u);
+            V3 dd = normalize(u * (float)std::cos(r1) * r2s + v * (float)std::sin(r1) * r2s +
+                              w * (float)std::sqrt(1 - r2));
+            rStart = c.location - rDir * 0.001f;
+            next_dir = dd;
+        }
+        rDir = next_dir;
+        if (st && finite3(rDir)) st->continued++;
+    }
+}
+
+/* Camera ctor + camera matrix: camera.cpp:43-47, pathtracer.cpp:216-221 with
+ * glm::rotate (gtc/matrix_transform) restated.  Column-major 3x3. */
+struct Mat3 {
+    V3 c0, c1, c2;
+};
+inline Mat3 rotate(const Mat3 &m, float angle, V3 axis_in) {
+    float c = std::cos(angle), s = std::sin(angle);
+    V3 axis = normalize(axis_in);
+    V3 temp = axis * (1.0f - c);
+    float r00 = c + temp.x * axis.x, r01 = temp.x * axis.y + s * axis.z, r02 = temp.x * axis.z - s * axis.y;
+    float r10 = temp.y * axis.x - s * axis.z, r11 = c + temp.y * axis.y, r12 = temp.y * axis.z + s * axis.x;
+    float r20 = temp.z * axis.x + s * axis.y, r21 = temp.z * axis.y - s * axis.x, r22 = c + temp.z * axis.z;
+    Mat3 out;
+    out.c0 = m.c0 * r00 + m.c1 * r01 + m.c2 * r02;
+    out.c1 = m.c0 * r10 + m.c1 * r11 + m.c2 * r12;
+    out.c2 = m.c0 * r20 + m.c1 * r21 + m.c2 * r22;
+    return out;
+}
+inline Mat3 camera_matrix(const vmx_camera &cam) {
+    /* camera.cpp:43-47: double arithmetic narrowed to float */
+    float rx = (float)(-cam.rotation_deg[0] * 3.1415926535 / 180);
+    float ry = (float)(-cam.rotation_deg[1] * 3.1415926535 / 180);
+    float rz = (float)(cam.rotation_deg[2] * 3.1415926535 / 180);
+    Mat3 m = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+    m = rotate(m, ry, v3(0, 1, 0)); /* pathtracer.cpp:219 */
+    m = rotate(m, rx, v3(1, 0, 0)); /* :220 */
+    m = rotate(m, rz, v3(0, 0, 1)); /* :221 */
+    return m;
+}
+
+/* pathtracer.cpp:251-280 */
+inline V3 primary_dir(const vmx_camera &cam, const Mat3 &M, uint64_t p, uint32_t sampleX,
+                      uint32_t sampleY, float jx, float jy) {
+    uint32_t W = cam.image_res[0], H = cam.image_res[1];
+    float hx = (float)(((float(p % W) + (sampleX * 0.5f - 0.5f) + jx - 0.25) / W) - 0.5);
+    float hy = (float)(((float(p / W) + (sampleY * 0.5f - 0.5f) + jy - 0.25) / H) - 0.5);
+    float bx = hx * cam.back_size[0];
+    float by = hy * cam.back_size[1];
+    float gx = bx, gy = -by, gz = -cam.back_distance; /* gridPane, w = 1 */
+    /* mat4*vec4 = (m0*x + m1*y) + (m2*z + m3*w); m3 = (0,0,0,1) */
+    V3 raw = (M.c0 * gx + M.c1 * gy) + (M.c2 * gz + v3(0, 0, 0) * 1.0f);
+    float w = (0.f * gx + 0.f * gy) + (0.f * gz + 1.f * 1.0f);
+    return normalize(raw / w);
+}
+
+template <class Rng, class InitFn>
+void render_rows(const orc_scene &sc, const vmx_camera &cam, const vmx_opts &opts, float *out,
+                 vmx_stats *stats, int threads, InitFn init_rng) {
+    const uint32_t W = cam.image_res[0], H = cam.image_res[1], spp = cam.rays_per_pixel;
+    const uint64_t npix = (uint64_t)W * H;
+    const Mat3 M = camera_matrix(cam);
+    const V3 origin = v3(cam.position[0], cam.position[1], cam.position[2]);
+    const bool count_nodes = opts.collect_counters != 0;
+    uint64_t t_prim = 0, t_sec = 0, t_samples = 0, t_inner = 0, t_tris = 0, t_hits = 0, t_cont = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel reduction(+ : t_prim, t_sec, t_samples, t_inner, t_tris, t_hits, t_cont)
+    {
+        Rng rng;
+        PathStats st;
+#pragma omp for schedule(dynamic, 1)
+        for (uint64_t p = 0; p < npix; ++p) { /* pathtracer.cpp:226-227 */
+            V4 accum = {0, 0, 0, 0};
+            uint32_t nTotal = 0;
+            for (uint16_t sx = 0; sx < 2; ++sx) {
+                for (uint16_t sy = 0; sy < 2; ++sy) {
+                    for (uint32_t sz = 0; sz < (spp / 4); ++sz) { /* :242-247 */
+                        ++nTotal;
+                        uint32_t k = (uint32_t)(sx * 2 + sy) * (spp / 4) + sz;
+                        init_rng(rng, p, k);
+                        float jx = rng.jitter(); /* :251 */
+                        float jy = rng.jitter(); /* :252 */
+                        V3 dir = primary_dir(cam, M, p, sx, sy, jx, jy);
+                        V4 s = radiance(sc, origin, dir, rng, opts.sampling, &st, count_nodes);
+                        accum = accum + s; /* :283 */
+                        if (opts.early_stop && nTotal > std::sqrt((double)spp)) { /* :290-311 */
+                            V3 a = v3(accum.x, accum.y, accum.z) / float(nTotal);
+                            V3 b = v3(accum.x + s.x, accum.y + s.y, accum.z + s.z) / float(nTotal + 1);
+                            if (std::fabs(length(a - b)) < 0.00001f) break;
+                        }
+                    }
+                }
+            }
+            float *px = out + p * 5; /* :318-324, camera.cpp:106-113 */
+            px[0] = std::max(std::min(accum.x / nTotal, 1.f), 0.f);
+            px[1] = std::max(std::min(accum.y / nTotal, 1.f), 0.f);
+            px[2] = std::max(std::min(accum.z / nTotal, 1.f), 0.f);
+            px[3] = 1.f;
+            px[4] = (float)nTotal;
+            t_samples += nTotal;
+        }
+        t_prim += st.rays_primary;
+        t_sec += st.rays_secondary;
+        t_inner += st.cnt.inner_visits;
+        t_tris += st.cnt.tri_tests;
+        t_hits += st.tri_hits;
+        t_cont += st.continued;
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays_primary = t_prim;
+        stats->rays_secondary = t_sec;
+        stats->samples = t_samples;
+        /* the oracle does not split counters by stage: totals go to `primary` */
+        stats->primary.rays = t_prim + t_sec;
+        stats->primary.inner_visits = t_inner;
+        stats->primary.tri_tests = t_tris;
+        stats->primary.tri_hits = t_hits;
+        stats->primary.continued = t_cont;
+    }
+}
+
+} // namespace
+
+/* ------------------------------------------------------------------ */
+/* C API                                                               */
+/* ------------------------------------------------------------------ */
+extern "C" {
+
+const char *orc_build_flags(void) {
+#ifdef ORC_BUILD_FLAGS
+    return ORC_BUILD_FLAGS;
+#else
+    return "unknown";
+#endif
+}
+
+const vmx_sphere *orc_default_spheres(uint32_t *count) {
+    if (count) *count = 8;
+    return kDefaultSpheres;
+}
+
+orc_scene *orc_scene_create(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
+                            const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size) {
+    if (!pos || !nrm || ntris == 0) return nullptr;
+    orc_scene *sc = new orc_scene();
+    sc->leaf_size = leaf_size ? leaf_size : 4;
+    sc->tris.resize(ntris);
+    for (uint32_t i = 0; i < ntris; ++i) {
+        Tri &t = sc->tris[i];
+        const float *p = pos + (size_t)i * 9, *n = nrm + (size_t)i * 9;
+        t.v0 = v3(p[0], p[1], p[2]);
+        t.v1 = v3(p[3], p[4], p[5]);
+        t.v2 = v3(p[6], p[7], p[8]);
+        t.n0 = v3(n[0], n[1], n[2]);
+        t.n1 = v3(n[3], n[4], n[5]);
+        t.n2 = v3(n[6], n[7], n[8]);
+        if (uv) {
+            const float *q = uv + (size_t)i * 6;
+            t.t0 = {q[0], q[1]};
+            t.t1 = {q[2], q[3]};
+            t.t2 = {q[4], q[5]};
+        } else {
+            t.t0 = t.t1 = t.t2 = {0, 0};
+        }
+        t.id = i;
+    }
+    sc->prims.resize(ntris);
+    for (uint32_t i = 0; i < ntris; ++i) sc->prims[i] = &sc->tris[i];
+    if (spheres == nullptr && nspheres == 0)
+        sc->spheres.assign(kDefaultSpheres, kDefaultSpheres + 8);
+    else
+        sc->spheres.assign(spheres, spheres + nspheres);
+    build_bvh(*sc);
+    return sc;
+}
+
+void orc_scene_destroy(orc_scene *sc) { delete sc; }
+
+void orc_scene_describe(const orc_scene *sc, uint32_t *n_nodes, uint32_t *n_leaves,
+                        uint32_t *max_depth) {
+    if (n_nodes) *n_nodes = (uint32_t)sc->nodes.size();
+    if (n_leaves) *n_leaves = sc->n_leaves;
+    if (max_depth) *max_depth = sc->max_depth;
+}
+
+void orc_scene_bvh(const orc_scene *sc, uint32_t *start, uint32_t *nprims, uint32_t *right_offset,
+                   float *bbox, uint32_t *prim_order) {
+    for (size_t i = 0; i < sc->nodes.size(); ++i) {
+        const FlatNode &n = sc->nodes[i];
+        if (start) start[i] = n.start;
+        if (nprims) nprims[i] = n.nprims;
+        if (right_offset) right_offset[i] = n.right_offset;
+        if (bbox) {
+            float *b = bbox + i * 6;
+            b[0] = n.box.lo.x, b[1] = n.box.lo.y, b[2] = n.box.lo.z;
+            b[3] = n.box.hi.x, b[4] = n.box.hi.y, b[5] = n.box.hi.z;
+        }
+    }
+    if (prim_order)
+        for (size_t i = 0; i < sc->prims.size(); ++i) prim_order[i] = sc->prims[i]->id;
+}
+
+void orc_trace(const orc_scene *sc, const float *o, const float *d, uint32_t n, int32_t *tri_id,
+               float *t, orc_trace_counters *counters) {
+    uint64_t iv = 0, tt = 0, pp = 0, ms = 0;
+#pragma omp parallel for schedule(static) reduction(+ : iv, tt, pp) reduction(max : ms)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        RayQ r = make_ray(v3(o[i * 3], o[i * 3 + 1], o[i * 3 + 2]), v3(d[i * 3], d[i * 3 + 1], d[i * 3 + 2]));
+        Counters c;
+        float bt;
+        const Tri *obj;
+        bool h = bvh_nearest(*sc, r, &bt, &obj, counters ? &c : nullptr);
+        tri_id[i] = h ? (int32_t)obj->id : -1;
+        t[i] = bt;
+        iv += c.inner_visits, tt += c.tri_tests, pp += c.pops;
+        ms = std::max(ms, c.max_stack);
+    }
+    if (counters) {
+        counters->inner_visits = iv;
+        counters->tri_tests = tt;
+        counters->pops = pp;
+        counters->max_stack = ms;
+    }
+}
+
+void orc_raycast(const orc_scene *sc, const float *o, const float *d, uint32_t n, vmx_rayhit *out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        CastOut c = ray_cast(*sc, v3(o[i * 3], o[i * 3 + 1], o[i * 3 + 2]),
+                             v3(d[i * 3], d[i * 3 + 1], d[i * 3 + 2]), nullptr);
+        vmx_rayhit &h = out[i];
+        std::memset(&h, 0, sizeof(h));
+        h.location[0] = c.location.x, h.location[1] = c.location.y, h.location[2] = c.location.z;
+        h.distance = c.distance;
+        h.normal[0] = c.normal.x, h.normal[1] = c.normal.y, h.normal[2] = c.normal.z;
+        h.tri_id = c.tri_id;
+        h.uv[0] = c.uv.x, h.uv[1] = c.uv.y;
+        h.tri_t = c.tri_t;
+        h.flags = (c.hit ? 1u : 0u) | (c.material ? 2u : 0u);
+        h.colour[0] = c.colour.x, h.colour[1] = c.colour.y, h.colour[2] = c.colour.z;
+    }
+}
+
+void orc_radiance(const orc_scene *sc, const float *o, const float *d, uint32_t n,
+                  const vmx_opts *opts, float *out4, vmx_stats *stats) {
+    uint64_t t_prim = 0, t_sec = 0, t_inner = 0, t_tris = 0, t_hits = 0, t_cont = 0;
+    const bool count_nodes = opts->collect_counters != 0;
+#pragma omp parallel for schedule(static) reduction(+ : t_prim, t_sec, t_inner, t_tris, t_hits, t_cont)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        Xoshiro rng;
+        rng.init(opts->seed, (uint32_t)i, 0);
+        (void)rng.next(); /* the two pixel-jitter draws of the stream are skipped */
+        (void)rng.next();
+        PathStats st;
+        V4 r = radiance(*sc, v3(o[i * 3], o[i * 3 + 1], o[i * 3 + 2]),
+                        v3(d[i * 3], d[i * 3 + 1], d[i * 3 + 2]), rng, opts->sampling, &st, count_nodes);
+        out4[i * 4] = r.x, out4[i * 4 + 1] = r.y, out4[i * 4 + 2] = r.z, out4[i * 4 + 3] = r.w;
+        t_prim += st.rays_primary, t_sec += st.rays_secondary, t_inner += st.cnt.inner_visits;
+        t_tris += st.cnt.tri_tests, t_hits += st.tri_hits, t_cont += st.continued;
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays_primary = t_prim, stats->rays_secondary = t_sec;
+        stats->primary.rays = t_prim + t_sec, stats->primary.inner_visits = t_inner;
+        stats->primary.tri_tests = t_tris, stats->primary.tri_hits = t_hits;
+        stats->primary.continued = t_cont;
+        stats->samples = n;
+    }
+}
+
+void orc_radiance_mt(const orc_scene *sc, const float *o, const float *d, uint32_t n,
+                     const uint64_t *seeds, uint32_t sampling, float *out4) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        MtRng rng;
+        rng.eng.seed(seeds[i]);
+        V4 r = radiance(*sc, v3(o[i * 3], o[i * 3 + 1], o[i * 3 + 2]),
+                        v3(d[i * 3], d[i * 3 + 1], d[i * 3 + 2]), rng, sampling, nullptr, false);
+        out4[i * 4] = r.x, out4[i * 4 + 1] = r.y, out4[i * 4 + 2] = r.z, out4[i * 4 + 3] = r.w;
+    }
+}
+
+void orc_camera_matrix(const vmx_camera *cam, float m9[9]) {
+    Mat3 m = camera_matrix(*cam);
+    m9[0] = m.c0.x, m9[1] = m.c0.y, m9[2] = m.c0.z;
+    m9[3] = m.c1.x, m9[4] = m.c1.y, m9[5] = m.c1.z;
+    m9[6] = m.c2.x, m9[7] = m.c2.y, m9[8] = m.c2.z;
+}
+
+void orc_primary_rays(const vmx_camera *cam, const vmx_opts *opts, uint32_t k, float *o, float *d) {
+    const uint32_t W = cam->image_res[0], H = cam->image_res[1], Q = cam->rays_per_pixel / 4;
+    const Mat3 M = camera_matrix(*cam);
+    const uint32_t s = Q ? k / Q : 0, sx = s >> 1, sy = s & 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < (int64_t)W * H; ++p) {
+        Xoshiro rng;
+        rng.init(opts->seed, (uint32_t)p, k);
+        float jx = rng.jitter(), jy = rng.jitter();
+        V3 dir = primary_dir(*cam, M, (uint64_t)p, sx, sy, jx, jy);
+        o[p * 3] = cam->position[0], o[p * 3 + 1] = cam->position[1], o[p * 3 + 2] = cam->position[2];
+        d[p * 3] = dir.x, d[p * 3 + 1] = dir.y, d[p * 3 + 2] = dir.z;
+    }
+}
+
+void orc_stream(uint64_t seed, uint32_t pixel, uint32_t k, uint32_t n, uint64_t *out) {
+    Xoshiro r;
+    r.init(seed, pixel, k);
+    for (uint32_t i = 0; i < n; ++i) out[i] = r.next();
+}
+
+uint64_t orc_splitmix64(uint64_t *state) { return splitmix64(*state); }
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orc_render(const orc_scene *sc, const vmx_camera *cam, const vmx_opts *opts, int rng_mode,
+                int threads, float *out_rgbaz, vmx_stats *stats) {
+    if (rng_mode == ORC_RNG_MT19937_64) {
+        const uint64_t seed = opts->seed;
+        /* one engine per thread, seeded once and carried across pixels,
+         * pathtracer.cpp:231 (the reference seeds from std::random_device;
+         * here seed + thread id) */
+        render_rows<MtRng>(*sc, *cam, *opts, out_rgbaz, stats, threads,
+                           [seed](MtRng &r, uint64_t, uint32_t) {
+                               if (r.seeded) return;
+#ifdef _OPENMP
+                               r.eng.seed(seed + (uint64_t)omp_get_thread_num());
+#else
+                               r.eng.seed(seed);
+#endif
+                               r.seeded = true;
+                           });
+    } else {
+        const uint64_t seed = opts->seed;
+        render_rows<Xoshiro>(*sc, *cam, *opts, out_rgbaz, stats, threads,
+                             [seed](Xoshiro &r, uint64_t p, uint32_t k) { r.init(seed, (uint32_t)p, k); });
+    }
+}
+
+} /* extern "C" */

@@ -1,0 +1,31 @@
+// bvh_build.h — host-side BVH construction with the reference's topology
+// (core/accelerators/bvh.cpp:179-279) and its flattening into the 2-wide
+// device records of vmx_device.h.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "vmx_device.h"
+
+namespace vmx {
+
+struct HostBvh {
+    // reference flat layout (bvh.h:11-14), DFS pre-order, left child = i+1
+    std::vector<uint32_t> start, nprims, right_offset;
+    std::vector<float> bbox;          // [n_nodes*6] min,max
+    std::vector<uint32_t> prim_order; // final build_prims permutation: leaf slot -> triangle id
+    uint32_t n_leaves = 0;
+    uint32_t max_depth = 0;
+    // device layout
+    std::vector<InnerRecord> inner;
+    std::vector<TriRecord> tris;
+    std::vector<AttrRecord> attrs;
+    uint32_t root_ref = 0;
+};
+
+// pos/nrm: [ntris*9], uv: [ntris*6] or nullptr.  Returns false and sets `err`
+// on invalid input (non-finite vertices, too many triangles, tree too deep).
+bool build_bvh(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
+               uint32_t leaf_size, HostBvh &out, std::string &err);
+
+}  // namespace vmx

@@ -1,0 +1,772 @@
+// vmx_api.cpp — implementation of the C ABI in include/vermilion_hip.h.
+//
+// Host orchestration only: BVH build (bvh_build.cpp), uploads, the pass loop
+// of the wavefront pipeline, statistics.  All arithmetic that defines results
+// runs in the gfx950 kernels (vmx_kernels.hip); there is no CPU rendering
+// path here — without a HIP device every compute entry point fails.
+#include "../../include/vermilion_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "vmx_device.h"
+#include "vmx_kernels.h"
+
+using namespace vmx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(VMX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+#define LAUNCH_TRY(expr)                                                                           \
+    do {                                                                                           \
+        int e_ = (expr);                                                                           \
+        if (e_ != 0)                                                                               \
+            return fail(VMX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e_)); \
+    } while (0)
+
+// The reference's eight spheres, core/engines/meshEngine.cpp:377-500.
+// sizeOfSpheres = 1e7*5 is a double narrowed to float by glm::vec3 / the float
+// `rad` parameter (meshEngine.cpp:182, 425).
+const vmx_sphere kReferenceSpheres[8] = {
+    {{15.f, 140.f, 25.f}, 3.5f, {0.f * 15.f, .5f * 15.f, 1.0f * 15.f}, VMX_SPHERE_EMIT, {-55.f, 350.f, -150.f}, -1.f},
+    {{0.f, 3300.f, 1300.f}, 250.f, {1.0f * 15.2f, 1.0f * 15.2f, 1.0f * 15.2f}, VMX_SPHERE_EMIT, {500.f, 800.f, 1300.f}, 1.f},
+    {{0.f, (float)(-5e7), 0.f}, (float)5e7, {0, 0, 0}, 0u, {0.f, (float)(-5e7), 0.f}, 1.f},
+    {{0.f, (float)(5e7 + 1000), 0.f}, (float)5e7, {0, 0, 0}, 0u, {0.f, (float)(5e7 + 1000), 0.f}, 1.f},
+    {{(float)(-5e7 + 2000), 0.f, 0.f}, (float)5e7, {0, 0, 0}, 0u, {(float)(-5e7 + 2000), 0.f, 0.f}, -1.f},
+    {{(float)(5e7 - 2000), 0.f, 0.f}, (float)5e7, {0, 0, 0}, 0u, {(float)(5e7 - 2000), 0.f, 0.f}, -1.f},
+    {{0.f, 0.f, (float)(-5e7 + 2000)}, (float)5e7, {0, 0, 0}, 0u, {0.f, 0.f, (float)(-5e7 + 2000)}, -1.f},
+    {{0.f, 0.f, (float)(5e7 - 2000)}, (float)5e7, {0, 0, 0}, 0u, {0.f, 0.f, (float)(5e7 - 2000)}, 1.f},
+};
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n && p) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) return (int)e;
+        n = count;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    void reset() { used = 0; }
+    void release() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        used = 0;
+    }
+};
+
+// per-scene reusable device workspace for the render pipeline
+struct Workspace {
+    DevBuf<unsigned char> queue_planes[2];
+    DevBuf<unsigned int> queue_counts;  // 2 * kSubQueues * 32
+    DevBuf<unsigned char> rad;          // float4 per path of a pass
+    DevBuf<unsigned char> accum;        // float4 per local pixel
+    DevBuf<unsigned int> count, cursor, active[2], next_count;
+    DevBuf<DevCounters> counters;
+    DevBuf<float> out;  // frame buffer for host-output renders
+    std::vector<unsigned int> order;
+    uint32_t order_w = 0, order_rows = 0;
+    EventPool events;
+    void release() {
+        queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release();
+        accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
+        next_count.release(), counters.release(), out.release(), events.release();
+    }
+};
+
+}  // namespace
+
+struct vmx_scene {
+    int device = 0;
+    int num_cus = 0;
+    HostBvh bvh;
+    uint32_t ntris = 0, leaf_size = 4;
+    std::vector<vmx_sphere> spheres;
+    DevBuf<InnerRecord> d_inner;
+    DevBuf<TriRecord> d_tris;
+    DevBuf<AttrRecord> d_attrs;
+    DevBuf<SphereDev> d_spheres;
+    SceneDev dev{};
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    Workspace ws;
+    uint32_t block = 256;
+};
+
+namespace {
+
+uint32_t local_rows_of(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world) {
+    if (world <= 1) return height;
+    uint32_t rows = 0;
+    const uint32_t n_stripes = (height + stripe_rows - 1) / stripe_rows;
+    for (uint32_t s = rank; s < n_stripes; s += world)
+        rows += std::min(stripe_rows, height - s * stripe_rows);
+    return rows;
+}
+
+// Camera ctor conversion (camera.cpp:43-47) + camera matrix (pathtracer.cpp:216-221).
+// glm::rotate (gtc/matrix_transform) on the upper-left 3x3; column-major.
+struct M3 {
+    float c[3][3];
+};
+M3 rotate_axis(const M3 &m, float angle, float ax, float ay, float az) {
+    const float c = std::cos(angle), s = std::sin(angle);
+    const float inv = 1.0f / std::sqrt((ax * ax + ay * ay) + az * az);  // glm::normalize
+    const float a[3] = {ax * inv, ay * inv, az * inv};
+    const float t[3] = {a[0] * (1.0f - c), a[1] * (1.0f - c), a[2] * (1.0f - c)};
+    float r[3][3];
+    r[0][0] = c + t[0] * a[0];
+    r[0][1] = t[0] * a[1] + s * a[2];
+    r[0][2] = t[0] * a[2] - s * a[1];
+    r[1][0] = t[1] * a[0] - s * a[2];
+    r[1][1] = c + t[1] * a[1];
+    r[1][2] = t[1] * a[2] + s * a[0];
+    r[2][0] = t[2] * a[0] + s * a[1];
+    r[2][1] = t[2] * a[1] - s * a[0];
+    r[2][2] = c + t[2] * a[2];
+    M3 out;
+    for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row)
+            out.c[col][row] = (m.c[0][row] * r[col][0] + m.c[1][row] * r[col][1]) + m.c[2][row] * r[col][2];
+    return out;
+}
+
+int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
+    const uint32_t W = cam.image_res[0], H = cam.image_res[1], spp = cam.rays_per_pixel;
+    if (W == 0 || H == 0) return fail(VMX_ERR_INVALID, "image resolution must be non-zero");
+    if ((uint64_t)W * H > 0x7fffffffull / 8) return fail(VMX_ERR_INVALID, "image too large");
+    if (spp < 4)
+        return fail(VMX_ERR_INVALID,
+                    "rays_per_pixel < 4 renders no sample (uSamplesPerPixel/4 == 0, pathtracer.cpp:247)");
+    if (o.sampling > VMX_SAMPLING_CORRECTED) return fail(VMX_ERR_INVALID, "unknown sampling mode");
+    const float rx = (float)(-cam.rotation_deg[0] * 3.1415926535 / 180);
+    const float ry = (float)(-cam.rotation_deg[1] * 3.1415926535 / 180);
+    const float rz = (float)(cam.rotation_deg[2] * 3.1415926535 / 180);
+    M3 m = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
+    m = rotate_axis(m, ry, 0, 1, 0);
+    m = rotate_axis(m, rx, 1, 0, 0);
+    m = rotate_axis(m, rz, 0, 0, 1);
+    for (int col = 0; col < 3; ++col)
+        for (int row = 0; row < 3; ++row) fr.m[col * 3 + row] = m.c[col][row];
+    fr.px = cam.position[0], fr.py = cam.position[1], fr.pz = cam.position[2];
+    fr.film_dist = cam.back_distance;
+    fr.sensor_x = cam.back_size[0], fr.sensor_y = cam.back_size[1];
+    fr.width = W, fr.height = H;
+    fr.spp = spp, fr.quarter = spp / 4, fr.kmax = 4 * (spp / 4);
+    fr.nmin = (uint32_t)std::floor(std::sqrt((double)spp));
+    fr.early_stop = o.early_stop ? 1u : 0u;
+    fr.r2scale = o.sampling == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
+    fr.world = o.world <= 1 ? 1u : o.world;
+    fr.rank = o.world <= 1 ? 0u : o.rank;
+    fr.stripe_rows = o.stripe_rows ? o.stripe_rows : 16u;
+    if (fr.rank >= fr.world) return fail(VMX_ERR_INVALID, "rank must be < world");
+    fr.local_rows = local_rows_of(H, fr.stripe_rows, fr.rank, fr.world);
+    fr.seed = o.seed;
+    return VMX_OK;
+}
+
+int bind_device(const vmx_scene *sc) {
+    HIP_TRY(hipSetDevice(sc->device));
+    return VMX_OK;
+}
+
+LaunchCfg trace_cfg(const vmx_scene *sc, uint32_t work_items, int blocks_per_cu) {
+    LaunchCfg c;
+    c.block = sc->block;
+    c.lds_bytes = (sc->block / 64) * sc->dev.stack_entries * 512;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    uint32_t grid = (uint32_t)sc->num_cus * (uint32_t)blocks_per_cu;
+    grid = std::max(8u, grid & ~7u);
+    if (work_items < grid) grid = std::max(1u, work_items);
+    c.grid = grid;
+    return c;
+}
+
+// 8x8-pixel tiles, tile-major: consecutive slots are neighbouring pixels, so a
+// wave's 64 primary rays are coherent.
+void tile_order(uint32_t W, uint32_t rows, std::vector<unsigned int> &order) {
+    order.clear();
+    order.reserve((size_t)W * rows);
+    for (uint32_t ty = 0; ty < rows; ty += 8)
+        for (uint32_t tx = 0; tx < W; tx += 8)
+            for (uint32_t y = ty; y < std::min(ty + 8, rows); ++y)
+                for (uint32_t x = tx; x < std::min(tx + 8, W); ++x) order.push_back(y * W + x);
+}
+
+void stage_out(vmx_stage_stats &dst, const StageCounters &c) {
+    dst.rays = c.rays, dst.inner_visits = c.inner_visits, dst.tri_tests = c.tri_tests;
+    dst.tri_hits = c.tri_hits, dst.continued = c.continued;
+}
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+    int stage;
+};
+
+// reads the 16 sub-queue tails; returns total and the largest
+int read_counts(vmx_scene *sc, unsigned int *d_counts, hipStream_t s, uint64_t &total, uint32_t &largest) {
+    unsigned int h[kSubQueues * 32];
+    HIP_TRY(hipMemcpyAsync(h, d_counts, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    total = 0, largest = 0;
+    for (uint32_t q = 0; q < kSubQueues; ++q) {
+        total += h[q * 32];
+        largest = std::max(largest, h[q * 32]);
+    }
+    (void)sc;
+    return VMX_OK;
+}
+
+int run_queue(vmx_scene *sc, float r2scale, QueueDev q[2], int cur, void *rad, DevCounters *ctr, bool count,
+              uint32_t tail_threshold, hipStream_t s, std::vector<TimedLaunch> &timed, uint64_t &launches,
+              int bounce_blocks) {
+    Workspace &ws = sc->ws;
+    for (;;) {
+        uint64_t total;
+        uint32_t largest;
+        int rc = read_counts(sc, q[cur].counts, s, total, largest);
+        if (rc) return rc;
+        if (total == 0) break;
+        const uint32_t max_chunks = (largest + sc->block - 1) / sc->block;
+        const bool tail = total <= tail_threshold;
+        LaunchCfg cfg = trace_cfg(sc, max_chunks * kSubQueues, bounce_blocks);
+        if (!tail) LAUNCH_TRY(launch_zero_u32(q[cur ^ 1].counts, kSubQueues * 32, s));
+        TimedLaunch tl{ws.events.get(), ws.events.get(), 1};
+        if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(tl.a, s));
+        LAUNCH_TRY(launch_bounce(sc->dev, r2scale, q[cur], max_chunks, q[cur ^ 1], rad, ctr, count, tail, false,
+                                 cfg, s));
+        HIP_TRY(hipEventRecord(tl.b, s));
+        timed.push_back(tl);
+        launches += tail ? 1 : 2;
+        if (tail) break;
+        cur ^= 1;
+    }
+    return VMX_OK;
+}
+
+int ensure_queues(vmx_scene *sc, uint32_t sub_capacity, QueueDev q[2]) {
+    Workspace &ws = sc->ws;
+    const size_t cap = (size_t)sub_capacity * kSubQueues;
+    for (int i = 0; i < 2; ++i) {
+        int e = ws.queue_planes[i].ensure(cap * kPathBytes);
+        if (e) return fail(VMX_ERR_NOMEM, std::string("path queue: ") + hipGetErrorString((hipError_t)e));
+    }
+    int e = ws.queue_counts.ensure(2 * kSubQueues * 32);
+    if (e) return fail(VMX_ERR_NOMEM, "queue counters");
+    for (int i = 0; i < 2; ++i) {
+        q[i].planes = ws.queue_planes[i].p;
+        q[i].counts = ws.queue_counts.p + (size_t)i * kSubQueues * 32;
+        q[i].capacity = (uint32_t)cap;
+        q[i].sub_capacity = sub_capacity;
+    }
+    return VMX_OK;
+}
+
+int finish_stats(vmx_scene *sc, hipStream_t s, std::vector<TimedLaunch> &timed, hipEvent_t ev0, hipEvent_t ev1,
+                 vmx_stats *stats, uint64_t launches, uint64_t passes,
+                 std::chrono::steady_clock::time_point t0) {
+    Workspace &ws = sc->ws;
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!stats) return VMX_OK;
+    DevCounters h;
+    HIP_TRY(hipMemcpy(&h, ws.counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    std::memset(stats, 0, sizeof(*stats));
+    stage_out(stats->primary, h.stage[0]);
+    stage_out(stats->bounce, h.stage[1]);
+    stats->rays_primary = h.stage[0].rays;
+    stats->rays_secondary = h.stage[1].rays;
+    stats->samples = h.samples;
+    stats->samples_discarded = h.discarded;
+    stats->passes = passes;
+    stats->kernel_launches = launches;
+    for (auto &tl : timed) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, tl.a, tl.b));
+        vmx_stage_stats &st = tl.stage == 0 ? stats->primary : stats->bounce;
+        st.ms += ms;
+        st.launches++;
+    }
+    float ms = 0.f;
+    if (ev0 && ev1) HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    stats->ms_device = ms;
+    stats->ms_total =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return VMX_OK;
+}
+
+int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, float *d_out, hipStream_t s,
+                vmx_stats *stats) {
+    const auto t0 = std::chrono::steady_clock::now();
+    FrameDev fr;
+    int rc = make_frame(*cam, *opts, fr);
+    if (rc) return rc;
+    Workspace &ws = sc->ws;
+    const uint32_t W = fr.width, rows = fr.local_rows;
+    const uint32_t npix = W * rows;
+    const bool count = opts->collect_counters != 0;
+    const bool mega = opts->reserved[0] == 1;
+    if (npix == 0) {
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        return VMX_OK;
+    }
+
+    // pass sizing: at most max_paths paths in flight
+    const uint64_t max_paths = opts->reserved[1] ? opts->reserved[1] : (16ull << 20);
+    uint32_t smax = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
+    if (opts->samples_per_batch) smax = opts->samples_per_batch;
+    smax = std::min(smax, fr.kmax);
+
+    int pb = 1, bb = 1;
+    const uint32_t lds = (sc->block / 64) * sc->dev.stack_entries * 512;
+    HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, lds, count, &pb, &bb));
+    if (pb < 1 || bb < 1) return fail(VMX_ERR_HIP, "kernel does not fit on a CU (LDS stack too deep?)");
+
+    // buffers
+    const uint32_t n_pad_max = (npix + 63u) & ~63u;
+    const uint32_t tiles8_max = (((n_pad_max + sc->block - 1) / sc->block) + 7u) & ~7u;
+    const uint32_t sub_cap = ((tiles8_max * smax) / kSubQueues + 2) * sc->block;
+    QueueDev q[2];
+    rc = ensure_queues(sc, sub_cap, q);
+    if (rc) return rc;
+    if (ws.rad.ensure((size_t)n_pad_max * smax * 16) || ws.accum.ensure((size_t)npix * 16) ||
+        ws.count.ensure(npix) || ws.cursor.ensure(npix) || ws.active[0].ensure(npix) ||
+        ws.active[1].ensure(npix) || ws.next_count.ensure(32) || ws.counters.ensure(1))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the render workspace");
+    if (ws.order_w != W || ws.order_rows != rows) {
+        tile_order(W, rows, ws.order);
+        ws.order_w = W, ws.order_rows = rows;
+    }
+    PixelStateDev px{ws.accum.p, ws.count.p, ws.cursor.p};
+
+    ws.events.reset();
+    std::vector<TimedLaunch> timed;
+    uint64_t launches = 0, passes = 0;
+    hipEvent_t ev0 = ws.events.get(), ev1 = ws.events.get();
+    if (!ev0 || !ev1) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+
+    HIP_TRY(hipMemcpyAsync(ws.active[0].p, ws.order.data(), (size_t)npix * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(ev0, s));
+    HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
+    LAUNCH_TRY(launch_init_pixels(px, npix, s));
+    launches++;
+
+    uint32_t n_active = npix;
+    int cur_list = 0;
+    uint32_t n_uniform = 0;  // samples every active pixel has taken while no early stop was possible
+    uint32_t k_fixed = 0;    // fixed-spp mode: samples issued so far
+    const uint32_t tail_threshold = opts->reserved[2] ? opts->reserved[2] : (256u << 10);
+    while (n_active > 0) {
+        uint32_t S;
+        if (fr.early_stop) {
+            // no sample can trigger the early-stop rule before n = nmin+1 (pathtracer.cpp:292):
+            // up to there whole groups of samples are issued without speculation, after that one at a time
+            if (n_uniform < fr.nmin + 1 && n_uniform < fr.kmax) {
+                S = std::min({fr.nmin + 1 - n_uniform, smax, fr.kmax - n_uniform});
+                n_uniform += S;
+            } else {
+                S = 1;
+            }
+        } else {
+            if (k_fixed >= fr.kmax) break;
+            S = std::min(smax, fr.kmax - k_fixed);
+            k_fixed += S;
+        }
+        const uint32_t n_pad = (n_active + 63u) & ~63u;
+        const uint32_t tiles8 = (((n_pad + sc->block - 1) / sc->block) + 7u) & ~7u;
+        LaunchCfg cfg = trace_cfg(sc, tiles8 * S, pb);
+        if (!mega) LAUNCH_TRY(launch_zero_u32(q[0].counts, kSubQueues * 32, s));
+        TimedLaunch tl{ws.events.get(), ws.events.get(), 0};
+        if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(tl.a, s));
+        LAUNCH_TRY(launch_primary(sc->dev, fr, ws.active[cur_list].p, n_active, S, px, q[0], ws.rad.p,
+                                  ws.counters.p, count, mega, cfg, s));
+        HIP_TRY(hipEventRecord(tl.b, s));
+        timed.push_back(tl);
+        launches += 2;
+        if (!mega) {
+            rc = run_queue(sc, fr.r2scale, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed,
+                           launches, bb);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipMemsetAsync(ws.next_count.p, 0, 4, s));
+        LAUNCH_TRY(launch_resolve(fr, ws.active[cur_list].p, n_active, S, ws.rad.p, px, ws.active[cur_list ^ 1].p,
+                                  ws.next_count.p, d_out, ws.counters.p, s));
+        launches++;
+        passes++;
+        unsigned int h_next = 0;
+        HIP_TRY(hipMemcpyAsync(&h_next, ws.next_count.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        n_active = h_next;
+        cur_list ^= 1;
+    }
+    HIP_TRY(hipEventRecord(ev1, s));
+    return finish_stats(sc, s, timed, ev0, ev1, stats, launches, passes, t0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmx_abi_version(void) { return VMX_ABI_VERSION; }
+
+const char *vmx_last_error(void) { return g_err.c_str(); }
+
+int vmx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const vmx_sphere *vmx_default_spheres(uint32_t *count) {
+    if (count) *count = 8;
+    return kReferenceSpheres;
+}
+
+int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
+                     const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size, int device,
+                     vmx_scene **out) {
+    if (!out) return fail(VMX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!pos || !nrm || ntris == 0) return fail(VMX_ERR_INVALID, "scene needs positions, normals, ntris > 0");
+    if ((spheres == nullptr) != (nspheres == 0))
+        return fail(VMX_ERR_INVALID, "spheres/nspheres mismatch (NULL,0 selects the reference table)");
+    if (nspheres > kMaxSpheres) return fail(VMX_ERR_INVALID, "more than 16 spheres");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(VMX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(VMX_ERR_NO_DEVICE, "device ordinal out of range");
+
+    vmx_scene *sc = new vmx_scene();
+    sc->device = device;
+    sc->ntris = ntris;
+    sc->leaf_size = leaf_size ? leaf_size : 4;
+    std::string err;
+    if (!build_bvh(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err)) {
+        const int code = err.find("deeper") != std::string::npos ? VMX_ERR_DEPTH : VMX_ERR_INVALID;
+        delete sc;
+        return fail(code, err);
+    }
+    if (spheres)
+        sc->spheres.assign(spheres, spheres + nspheres);
+    else
+        sc->spheres.assign(kReferenceSpheres, kReferenceSpheres + 8);
+
+    auto bail = [&](int code, const std::string &m) {
+        vmx_scene_destroy(sc);
+        return fail(code, m);
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(VMX_ERR_HIP, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(VMX_ERR_HIP, "hipGetDeviceProperties");
+    sc->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(VMX_ERR_HIP, "hipStreamCreate failed");
+
+    std::vector<SphereDev> sd(sc->spheres.size());
+    for (size_t i = 0; i < sd.size(); ++i) {
+        const vmx_sphere &s = sc->spheres[i];
+        SphereDev &d = sd[i];
+        std::memset(&d, 0, sizeof(d));
+        d.cx = s.centre[0], d.cy = s.centre[1], d.cz = s.centre[2];
+        d.rad = s.radius;
+        d.rad2 = s.radius * s.radius;  // float product (meshEngine.cpp:188)
+        d.colr = s.colour[0], d.colg = s.colour[1], d.colb = s.colour[2];
+        d.ncx = s.normal_centre[0], d.ncy = s.normal_centre[1], d.ncz = s.normal_centre[2];
+        d.nsign = s.normal_sign < 0.f ? -1.f : 1.f;
+        d.flags = s.flags;
+    }
+    const HostBvh &b = sc->bvh;
+    if (sc->d_inner.ensure(std::max<size_t>(b.inner.size(), 1)) || sc->d_tris.ensure(b.tris.size()) ||
+        sc->d_attrs.ensure(b.attrs.size()) || sc->d_spheres.ensure(std::max<size_t>(sd.size(), 1)))
+        return bail(VMX_ERR_NOMEM, "hipMalloc failed for the scene");
+    if ((b.inner.size() && hipMemcpy(sc->d_inner.p, b.inner.data(), b.inner.size() * sizeof(InnerRecord),
+                                     hipMemcpyHostToDevice) != hipSuccess) ||
+        hipMemcpy(sc->d_tris.p, b.tris.data(), b.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice) !=
+            hipSuccess ||
+        hipMemcpy(sc->d_attrs.p, b.attrs.data(), b.attrs.size() * sizeof(AttrRecord), hipMemcpyHostToDevice) !=
+            hipSuccess ||
+        (sd.size() && hipMemcpy(sc->d_spheres.p, sd.data(), sd.size() * sizeof(SphereDev),
+                                hipMemcpyHostToDevice) != hipSuccess))
+        return bail(VMX_ERR_HIP, "scene upload failed");
+    sc->dev.inner = sc->d_inner.p;
+    sc->dev.tris = sc->d_tris.p;
+    sc->dev.attrs = sc->d_attrs.p;
+    sc->dev.spheres = sc->d_spheres.p;
+    sc->dev.root_ref = b.root_ref;
+    sc->dev.nspheres = (uint32_t)sd.size();
+    sc->dev.stack_entries = b.max_depth + 2;
+    sc->dev.ntris = ntris;
+    // LDS budget: shrink the block until one block's stacks fit in 64 KiB
+    sc->block = 256;
+    while (sc->block > 64 && (sc->block / 64) * sc->dev.stack_entries * 512 > 65536) sc->block /= 2;
+    *out = sc;
+    return VMX_OK;
+}
+
+int vmx_scene_destroy(vmx_scene *sc) {
+    if (!sc) return VMX_OK;
+    (void)hipSetDevice(sc->device);
+    sc->ws.release();
+    sc->d_inner.release(), sc->d_tris.release(), sc->d_attrs.release(), sc->d_spheres.release();
+    if (sc->stream) (void)hipStreamDestroy(sc->stream);
+    delete sc;
+    return VMX_OK;
+}
+
+int vmx_scene_describe(const vmx_scene *sc, vmx_scene_desc *out) {
+    if (!sc || !out) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::memset(out, 0, sizeof(*out));
+    out->ntris = sc->ntris;
+    out->nspheres = (uint32_t)sc->spheres.size();
+    out->leaf_size = sc->leaf_size;
+    out->n_nodes = (uint32_t)sc->bvh.start.size();
+    out->n_leaves = sc->bvh.n_leaves;
+    out->n_inner = (uint32_t)sc->bvh.inner.size();
+    out->max_depth = sc->bvh.max_depth;
+    out->stack_entries = sc->dev.stack_entries;
+    out->device_bytes = sc->bvh.inner.size() * sizeof(InnerRecord) + sc->bvh.tris.size() * sizeof(TriRecord) +
+                        sc->bvh.attrs.size() * sizeof(AttrRecord) + sc->spheres.size() * sizeof(SphereDev);
+    out->device = sc->device;
+    return VMX_OK;
+}
+
+int vmx_scene_bvh(const vmx_scene *sc, uint32_t *start, uint32_t *nprims, uint32_t *right_offset, float *bbox,
+                  uint32_t *prim_order) {
+    if (!sc) return fail(VMX_ERR_INVALID, "NULL scene");
+    const HostBvh &b = sc->bvh;
+    const size_t n = b.start.size();
+    if (start) std::memcpy(start, b.start.data(), n * 4);
+    if (nprims) std::memcpy(nprims, b.nprims.data(), n * 4);
+    if (right_offset) std::memcpy(right_offset, b.right_offset.data(), n * 4);
+    if (bbox) std::memcpy(bbox, b.bbox.data(), n * 24);
+    if (prim_order) std::memcpy(prim_order, b.prim_order.data(), b.prim_order.size() * 4);
+    return VMX_OK;
+}
+
+int vmx_trace(const vmx_scene *csc, const float *origin, const float *dir, uint32_t n, int32_t *tri_id,
+              float *t) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (!sc || !origin || !dir || !tri_id || !t) return fail(VMX_ERR_INVALID, "NULL argument");
+    if (n == 0) return VMX_OK;
+    std::lock_guard<std::mutex> lock(sc->mu);
+    int rc = bind_device(sc);
+    if (rc) return rc;
+    DevBuf<float> d_o, d_d, d_t;
+    DevBuf<int32_t> d_id;
+    if (d_o.ensure((size_t)n * 3) || d_d.ensure((size_t)n * 3) || d_t.ensure(n) || d_id.ensure(n))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the ray batch");
+    hipStream_t s = sc->stream;
+    auto cleanup = [&]() { d_o.release(), d_d.release(), d_t.release(), d_id.release(); };
+    hipError_t e = hipMemcpyAsync(d_o.p, origin, (size_t)n * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d.p, dir, (size_t)n * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        LaunchCfg cfg = trace_cfg(sc, (n + sc->block - 1) / sc->block, 4);
+        e = (hipError_t)launch_trace(sc->dev, d_o.p, d_d.p, n, d_id.p, d_t.p, nullptr, false, cfg, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(tri_id, d_id.p, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return fail(VMX_ERR_HIP, std::string("vmx_trace: ") + hipGetErrorString(e));
+    return VMX_OK;
+}
+
+int vmx_raycast(const vmx_scene *csc, const float *origin, const float *dir, uint32_t n, vmx_rayhit *out) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (!sc || !origin || !dir || !out) return fail(VMX_ERR_INVALID, "NULL argument");
+    if (n == 0) return VMX_OK;
+    static_assert(sizeof(vmx_rayhit) == 64, "vmx_rayhit must be 64 bytes");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    int rc = bind_device(sc);
+    if (rc) return rc;
+    DevBuf<float> d_o, d_d;
+    DevBuf<vmx_rayhit> d_out;
+    if (d_o.ensure((size_t)n * 3) || d_d.ensure((size_t)n * 3) || d_out.ensure(n))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the ray batch");
+    hipStream_t s = sc->stream;
+    hipError_t e = hipMemcpyAsync(d_o.p, origin, (size_t)n * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d.p, dir, (size_t)n * 12, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        LaunchCfg cfg = trace_cfg(sc, (n + sc->block - 1) / sc->block, 4);
+        e = (hipError_t)launch_raycast(sc->dev, d_o.p, d_d.p, n, d_out.p, cfg, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(vmx_rayhit), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    d_o.release(), d_d.release(), d_out.release();
+    if (e != hipSuccess) return fail(VMX_ERR_HIP, std::string("vmx_raycast: ") + hipGetErrorString(e));
+    return VMX_OK;
+}
+
+int vmx_primary_ids(const vmx_scene *csc, const vmx_camera *cam, const vmx_opts *opts, uint32_t k,
+                    int32_t *tri_id, float *t) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (!sc || !cam || !opts || !tri_id || !t) return fail(VMX_ERR_INVALID, "NULL argument");
+    FrameDev fr;
+    int rc = make_frame(*cam, *opts, fr);
+    if (rc) return rc;
+    if (k >= fr.kmax) return fail(VMX_ERR_INVALID, "sample index out of range");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    rc = bind_device(sc);
+    if (rc) return rc;
+    const uint32_t n = fr.width * fr.height;
+    DevBuf<float> d_t;
+    DevBuf<int32_t> d_id;
+    if (d_t.ensure(n) || d_id.ensure(n)) return fail(VMX_ERR_NOMEM, "hipMalloc failed");
+    hipStream_t s = sc->stream;
+    LaunchCfg cfg = trace_cfg(sc, (n + sc->block - 1) / sc->block, 4);
+    hipError_t e = (hipError_t)launch_primary_ids(sc->dev, fr, k, d_id.p, d_t.p, cfg, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(tri_id, d_id.p, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    d_t.release(), d_id.release();
+    if (e != hipSuccess) return fail(VMX_ERR_HIP, std::string("vmx_primary_ids: ") + hipGetErrorString(e));
+    return VMX_OK;
+}
+
+int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, uint32_t n, const vmx_opts *opts,
+                 float *out, vmx_stats *stats) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (!sc || !origin || !dir || !opts || !out) return fail(VMX_ERR_INVALID, "NULL argument");
+    if (opts->sampling > VMX_SAMPLING_CORRECTED) return fail(VMX_ERR_INVALID, "unknown sampling mode");
+    if (n == 0) return VMX_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> lock(sc->mu);
+    int rc = bind_device(sc);
+    if (rc) return rc;
+    Workspace &ws = sc->ws;
+    hipStream_t s = sc->stream;
+    const bool count = opts->collect_counters != 0;
+    const float r2scale = opts->sampling == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
+    // k_radiance_init: grid <= 4096 blocks of 256, sub-queue = block iteration % 16
+    const uint32_t blocks = (n + 255) / 256;
+    const uint32_t sub_cap = (blocks / kSubQueues + 2) * 256;
+    QueueDev q[2];
+    rc = ensure_queues(sc, sub_cap, q);
+    if (rc) return rc;
+    DevBuf<float> d_o, d_d;
+    if (d_o.ensure((size_t)n * 3) || d_d.ensure((size_t)n * 3) || ws.rad.ensure((size_t)n * 16) ||
+        ws.counters.ensure(1))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed");
+    int pb = 1, bb = 1;
+    const uint32_t lds = (sc->block / 64) * sc->dev.stack_entries * 512;
+    HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, lds, count, &pb, &bb));
+    ws.events.reset();
+    std::vector<TimedLaunch> timed;
+    uint64_t launches = 0;
+    hipEvent_t ev0 = ws.events.get(), ev1 = ws.events.get();
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(d_o.p, origin, (size_t)n * 12, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_d.p, dir, (size_t)n * 12, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(ev0, s));
+        HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
+        LAUNCH_TRY(launch_zero_u32(q[0].counts, kSubQueues * 32, s));
+        LAUNCH_TRY(launch_radiance_init(d_o.p, d_d.p, n, opts->seed, q[0], s));
+        launches += 2;
+        const uint32_t tail_threshold = opts->reserved[2] ? opts->reserved[2] : (256u << 10);
+        int r = run_queue(sc, r2scale, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed, launches, bb);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(ev1, s));
+        HIP_TRY(hipMemcpyAsync(out, ws.rad.p, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+        return finish_stats(sc, s, timed, ev0, ev1, stats, launches, 1, t0);
+    };
+    rc = body();
+    d_o.release(), d_d.release();
+    if (rc == VMX_OK && stats) stats->samples = n;
+    return rc;
+}
+
+int vmx_local_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world, uint32_t *rows) {
+    if (!rows) return fail(VMX_ERR_INVALID, "rows is NULL");
+    if (world > 1 && rank >= world) return fail(VMX_ERR_INVALID, "rank must be < world");
+    *rows = local_rows_of(height, stripe_rows ? stripe_rows : 16u, rank, world);
+    return VMX_OK;
+}
+
+int vmx_render_device(const vmx_scene *csc, const vmx_camera *cam, const vmx_opts *opts, void *d_out_rgbaz,
+                      void *stream, vmx_stats *stats) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (!sc || !cam || !opts || !d_out_rgbaz) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    int rc = bind_device(sc);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : sc->stream;
+    return render_impl(sc, cam, opts, (float *)d_out_rgbaz, s, stats);
+}
+
+int vmx_render(const vmx_scene *csc, const vmx_camera *cam, const vmx_opts *opts, float *out_rgbaz,
+               vmx_stats *stats) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (!sc || !cam || !opts || !out_rgbaz) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    int rc = bind_device(sc);
+    if (rc) return rc;
+    FrameDev fr;
+    rc = make_frame(*cam, *opts, fr);
+    if (rc) return rc;
+    const size_t nfloats = (size_t)fr.width * fr.local_rows * 5;
+    if (nfloats == 0) return VMX_OK;
+    if (sc->ws.out.ensure(nfloats)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the frame buffer");
+    rc = render_impl(sc, cam, opts, sc->ws.out.p, sc->stream, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out_rgbaz, sc->ws.out.p, nfloats * 4, hipMemcpyDeviceToHost));
+    return VMX_OK;
+}
+
+int vmx_assemble_device(const void *d_gathered, uint64_t rank_stride_floats, uint32_t width, uint32_t height,
+                        uint32_t stripe_rows, uint32_t world, void *d_frame, int device, void *stream) {
+    if (!d_gathered || !d_frame || width == 0 || height == 0 || world == 0)
+        return fail(VMX_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    LAUNCH_TRY(launch_assemble((const float *)d_gathered, rank_stride_floats, width, height,
+                               stripe_rows ? stripe_rows : 16u, world, (float *)d_frame, stream));
+    if (!stream) HIP_TRY(hipDeviceSynchronize());
+    return VMX_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,108 @@
+// vmx_device.h — structures shared by the host orchestration (vmx_api.cpp) and
+// the gfx950 kernels (vmx_kernels.hip).  Plain C++; no HIP types beyond float4.
+#pragma once
+#include <stdint.h>
+
+namespace vmx {
+
+// ---- BVH child reference ---------------------------------------------------
+// bit 31 set  : leaf,  bits 0..25 = first triangle (leaf order), bits 26..30 = count
+// bit 31 clear: index of a 2-wide inner record
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kLeafStartMask = 0x03FFFFFFu;
+constexpr uint32_t kLeafCountShift = 26;
+constexpr uint32_t kMaxLeafSize = 31;
+constexpr uint32_t kMaxTris = kLeafStartMask + 1;
+constexpr uint32_t kMaxSpheres = 16;
+constexpr uint32_t kMaxStack = 64;  // bvh.cpp:54
+
+// One 2-wide inner record = 64 bytes = 4 x float4, read by one lane as four
+// 16-byte loads from one base address:
+//   q0 = (L.min.x, L.min.y, L.min.z, L.max.x)
+//   q1 = (L.max.y, L.max.z, R.min.x, R.min.y)
+//   q2 = (R.min.z, R.max.x, R.max.y, R.max.z)
+//   q3 = (bits(left ref), bits(right ref), 0, 0)
+// L is the reference's node ni+1, R is node ni+rightOffset (bvh.cpp:99-100).
+struct InnerRecord {
+    float lmin[3];
+    float lmax[3];
+    float rmin[3];
+    float rmax[3];
+    uint32_t left, right, pad0, pad1;
+};
+static_assert(sizeof(InnerRecord) == 64, "inner record must be 64 bytes");
+
+// Intersection record, leaf order, 48 bytes = 3 x float4:
+//   q0 = (v0.x, v0.y, v0.z, e1.x)  q1 = (e1.y, e1.z, e2.x, e2.y)  q2 = (e2.z, bits(id), 0, 0)
+// e1 = v1 - v0, e2 = v2 - v0 are the values triangle.cpp:12-13 recomputes per test.
+struct TriRecord {
+    float v0[3];
+    float e1[3];
+    float e2[3];
+    uint32_t id;
+    uint32_t pad[2];
+};
+static_assert(sizeof(TriRecord) == 48, "tri record must be 48 bytes");
+
+// Shading attributes, leaf order, 64 bytes = 4 x float4 (triangle.cpp:81-82 inputs)
+struct AttrRecord {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    float pad;
+};
+static_assert(sizeof(AttrRecord) == 64, "attr record must be 64 bytes");
+
+struct SphereDev {
+    float cx, cy, cz, rad;
+    float rad2;  // float product rad*rad (meshEngine.cpp:188)
+    float colr, colg, colb;
+    float ncx, ncy, ncz, nsign;
+    uint32_t flags, pad0, pad1, pad2;
+};
+static_assert(sizeof(SphereDev) == 64, "sphere record must be 64 bytes");
+
+struct SceneDev {
+    const void *inner;    // InnerRecord[n_inner]
+    const void *tris;     // TriRecord[ntris]
+    const void *attrs;    // AttrRecord[ntris]
+    const SphereDev *spheres;
+    uint32_t root_ref;
+    uint32_t nspheres;
+    uint32_t stack_entries;  // per-lane LDS stack entries (max tree depth + 2)
+    uint32_t ntris;
+};
+
+// per-stage device counters (one set for depth-0 steps, one for bounce steps)
+struct StageCounters {
+    unsigned long long rays, inner_visits, tri_tests, tri_hits, continued;
+};
+struct DevCounters {
+    StageCounters stage[2];
+    unsigned long long samples, discarded, pixels_done;
+};
+
+// Camera/frame constants for ray generation (pathtracer.cpp:216-221, 251-280)
+struct FrameDev {
+    float m[9];  // column-major 3x3 camera matrix
+    float px, py, pz;
+    float film_dist, sensor_x, sensor_y;
+    uint32_t width, height;       // full image
+    uint32_t spp, quarter;        // uSamplesPerPixel, spp/4
+    uint32_t kmax;                // 4*quarter
+    uint32_t nmin;                // floor(sqrt(spp)): early stop needs n > sqrt(spp)
+    uint32_t early_stop;
+    float r2scale;                // 10 (parity) or 1 (corrected)
+    uint32_t local_rows;          // rows owned by this rank
+    uint32_t stripe_rows, rank, world;
+    uint64_t seed;
+};
+
+// Path state across a bounce boundary: 6 planes of 16 bytes, plane p of slot s
+// at planes[p * capacity + s] (SoA of float4: every wave access is 1 KiB contiguous).
+//   P0 = (o.x, o.y, o.z, d.x)   P1 = (d.y, d.z, thr.r, thr.g)
+//   P2 = (thr.b, acc.r, acc.g, acc.b)   P3 = (acc.w, bits(depth), bits(dest), 0)
+//   P4 = rng s0,s1   P5 = rng s2,s3
+constexpr uint32_t kPathPlanes = 6;
+constexpr uint32_t kPathBytes = kPathPlanes * 16;
+
+}  // namespace vmx

@@ -1,0 +1,996 @@
+// vmx_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the path-tracing hot path.
+//
+// Compiled with -ffp-contract=off: every float operation rounds once, in the
+// operation order of the reference's GLM expressions, so that triangle IDs,
+// distances and whole frames are bit-identical to the CPU oracle.  Divide and
+// sqrt are hipcc's correctly rounded forms (its default).
+//
+// Kernels
+//   k_trace        BVH::getIntersection for explicit rays          (bvh.cpp:47-145)
+//   k_raycast      MeshEngine::RayCast for explicit rays           (meshEngine.cpp:239-509)
+//   k_primary      ray generation + RayCast + Radiance step at depth 0, path compaction
+//                                                                   (pathtracer.cpp:251-280, 36-196)
+//   k_bounce       RayCast + Radiance step for queued paths, path compaction
+//   k_resolve      per-pixel accumulation, early stop, pixel write (pathtracer.cpp:282-324)
+//
+// Execution model: persistent blocks stride over block-sized work items; the
+// item -> image-region map is XCD-aware (items b and b+8 run on one XCD and
+// are given neighbouring pixel tiles, so an XCD's 4 MiB L2 holds the part of
+// the BVH its rays walk).  Each lane owns one ray/path; its BVH stack lives in
+// LDS, lane-strided (entry e of lane l at [e*64 + l], 8 bytes: node ref +
+// entry distance), which is conflict-free for ds_read/write_b64 at any mix of
+// per-lane stack depths.  Surviving paths are compacted between bounces with a
+// wave ballot + prefix popcount and one atomic per wave on one of 16 sub-queue
+// tails.  No MFMA: there is no dense contraction in this workload.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "vmx_kernels.h"
+
+namespace vmx {
+namespace {
+
+constexpr float kInf = __builtin_huge_valf();
+
+struct Cnt {
+    uint32_t inner, tris;
+};
+
+// wave-uniform tallies, flushed once per wave at kernel exit
+struct Tally {
+    uint32_t rays[2], hits[2], cont[2];
+};
+
+__device__ __forceinline__ uint32_t lane_index() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// RNG: xoshiro256** keyed by (seed, pixel, sample)  — DESIGN.md "RNG"
+// ---------------------------------------------------------------------------
+struct Rng {
+    uint64_t s0, s1, s2, s3;
+};
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ void rng_init(Rng &r, uint64_t seed, uint32_t pixel, uint32_t k) {
+    uint64_t x = mix64(seed ^ (((uint64_t)pixel << 32) | (uint64_t)k));
+    x += 0x9E3779B97F4A7C15ull;
+    r.s0 = mix64(x);
+    x += 0x9E3779B97F4A7C15ull;
+    r.s1 = mix64(x);
+    x += 0x9E3779B97F4A7C15ull;
+    r.s2 = mix64(x);
+    x += 0x9E3779B97F4A7C15ull;
+    r.s3 = mix64(x);
+}
+
+__device__ __forceinline__ uint64_t rng_next(Rng &r) {
+    const uint64_t out = rotl64(r.s1 * 5, 7) * 9;
+    const uint64_t t = r.s1 << 17;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = rotl64(r.s3, 45);
+    return out;
+}
+
+// stands in for uniform_real_distribution<double>(0,1) (pathtracer.cpp:23)
+__device__ __forceinline__ double rng_u01(Rng &r) {
+    return __longlong_as_double((long long)(0x3FF0000000000000ull | (rng_next(r) >> 12))) - 1.0;
+}
+// stands in for uniform_real_distribution<float>(0,0.5) (pathtracer.cpp:230)
+__device__ __forceinline__ float rng_jitter(Rng &r) {
+    return (__uint_as_float(0x3F800000u | (uint32_t)(rng_next(r) >> 41)) - 1.0f) * 0.5f;
+}
+
+// ---------------------------------------------------------------------------
+// small vector helpers in GLM's operation order
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;  // glm::dot: tmp.x + tmp.y + tmp.z
+}
+// glm::normalize = v * (1 / sqrt(dot(v,v)))
+__device__ __forceinline__ void normalize3(float &x, float &y, float &z) {
+    const float s = 1.0f / sqrtf(dot3(x, y, z, x, y, z));
+    x = x * s;
+    y = y * s;
+    z = z * s;
+}
+// glm::cross(a, b)
+__device__ __forceinline__ void cross3(float ax, float ay, float az, float bx, float by, float bz,
+                                       float &cx, float &cy, float &cz) {
+    cx = ay * bz - by * az;
+    cy = az * bx - bz * ax;
+    cz = ax * by - bx * ay;
+}
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+    return (fabsf(x) < kInf) && (fabsf(y) < kInf) && (fabsf(z) < kInf);
+}
+
+// ---------------------------------------------------------------------------
+// BBox::intersect (bbox.cpp:70-83)
+// ---------------------------------------------------------------------------
+// Fast form: v_min/v_max.  Equal to the reference's compare-select form
+// whenever no slab product is NaN, which `exact == false` guarantees (finite
+// origin, finite non-zero reciprocal direction).
+__device__ __forceinline__ bool box_fast(float lx, float ly, float lz, float hx, float hy, float hz,
+                                         float ox, float oy, float oz, float ix, float iy, float iz,
+                                         float &tnear) {
+    const float t0x = (lx - ox) * ix, t0y = (ly - oy) * iy, t0z = (lz - oz) * iz;
+    const float t1x = (hx - ox) * ix, t1y = (hy - oy) * iy, t1z = (hz - oz) * iz;
+    const float n = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    const float f = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    tnear = n;
+    return n <= f;
+}
+// Exact form: glm::min/max = (b<a)?b:a / (a<b)?b:a, std::max/min likewise, NaN and all.
+__device__ __forceinline__ float sel_min(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float sel_max(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ bool box_exact(float lx, float ly, float lz, float hx, float hy, float hz,
+                                       float ox, float oy, float oz, float ix, float iy, float iz,
+                                       float &tnear) {
+    const float t0x = (lx - ox) * ix, t0y = (ly - oy) * iy, t0z = (lz - oz) * iz;
+    const float t1x = (hx - ox) * ix, t1y = (hy - oy) * iy, t1z = (hz - oz) * iz;
+    const float sx = sel_min(t0x, t1x), sy = sel_min(t0y, t1y), sz = sel_min(t0z, t1z);
+    const float bx = sel_max(t0x, t1x), by = sel_max(t0y, t1y), bz = sel_max(t0z, t1z);
+    const float n = sel_max(sel_max(sx, sy), sz);
+    const float f = sel_min(sel_min(bx, by), bz);
+    tnear = n;
+    return n <= f;
+}
+
+// ---------------------------------------------------------------------------
+// BVH::getIntersection, nearest hit (bvh.cpp:47-145) + Triangle::getIntersection
+// (triangle.cpp:4-54).  `stk` points at this lane's column of the wave's LDS stack.
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ void bvh_nearest(const SceneDev &sc, float ox, float oy, float oz, float dx,
+                                            float dy, float dz, uint2 *stk, float &best_out,
+                                            int &slot_out, Cnt &cnt) {
+    const float4 *__restrict__ inner = (const float4 *)sc.inner;
+    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // Ray.h:10
+    const bool exact = !(finite3(ix, iy, iz) && finite3(ox, oy, oz));
+
+    float best = 999999999.f;  // bvh.cpp:48
+    int slot = -1;
+    int sp = 0;
+    uint32_t cur = sc.root_ref;
+    float cur_near = -9999999.f;  // bvh.cpp:59
+    bool have = true;
+    for (;;) {
+        if (!have) {
+            if (sp == 0) break;
+            --sp;
+            const uint2 e = stk[sp * 64];
+            cur = e.x;
+            cur_near = __uint_as_float(e.y);
+        }
+        have = false;
+        if (cur_near > best) continue;  // bvh.cpp:69
+        if (cur & kLeafBit) {
+            const uint32_t first = cur & kLeafStartMask;
+            const uint32_t n = (cur >> kLeafCountShift) & 31u;
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t ti = (first + i) * 3;
+                const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
+                if (COUNT) cnt.tris++;
+                const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+                float px, py, pz;
+                cross3(dx, dy, dz, e2x, e2y, e2z, px, py, pz);
+                const float det = dot3(e1x, e1y, e1z, px, py, pz);
+                // (det < 1e-8 && det > -1e-8) in double  <=>  |det| <= float(1e-8)  (float(1e-8) < 1e-8)
+                const bool parallel = fabsf(det) <= 9.99999993922529e-09f;
+                const float inv_det = 1.0f / det;
+                const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+                const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
+                const bool u_out = (u < 0.0f) || (u > 1.0f);
+                float qx, qy, qz;
+                cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+                const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+                const bool v_out = (v < 0.0f) || (u + v > 1.0f);
+                const float dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+                const bool hit = !parallel && !u_out && !v_out && (dist > 0.0f);
+                if (hit && dist < best) {  // strict <: first tested wins ties (bvh.cpp:90)
+                    best = dist;
+                    slot = (int)(first + i);
+                }
+            }
+        } else {
+            const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2],
+                         q3 = inner[cur * 4 + 3];
+            if (COUNT) cnt.inner++;
+            float tn0, tn1;
+            bool h0, h1;
+            if (exact) {
+                h0 = box_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, tn0);
+                h1 = box_exact(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, tn1);
+            } else {
+                h0 = box_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, tn0);
+                h1 = box_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, tn1);
+            }
+            const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+            if (h0 && h1) {
+                // left assumed closer; swap if the right child is strictly closer (bvh.cpp:106-114)
+                const bool sw = tn1 < tn0;
+                const uint32_t closer = sw ? rref : lref, other = sw ? lref : rref;
+                const float nc = sw ? tn1 : tn0, no = sw ? tn0 : tn1;
+                stk[sp * 64] = make_uint2(other, __float_as_uint(no));  // farther first (bvh.cpp:120)
+                ++sp;
+                cur = closer;
+                cur_near = nc;
+                have = true;
+            } else if (h0) {
+                cur = lref;
+                cur_near = tn0;
+                have = true;
+            } else if (h1) {
+                cur = rref;
+                cur_near = tn1;
+                have = true;
+            }
+        }
+    }
+    best_out = best;
+    slot_out = slot;
+}
+
+// Triangle::getNormal (triangle.cpp:67-86) + normalize in the caller (meshEngine.cpp:369)
+__device__ __forceinline__ void tri_shading_normal(const SceneDev &sc, int slot, float hx, float hy,
+                                                   float hz, float &nx, float &ny, float &nz, float &uvx,
+                                                   float &uvy) {
+    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    const float4 *__restrict__ attrs = (const float4 *)sc.attrs;
+    const float4 a = tris[slot * 3], b = tris[slot * 3 + 1], c = tris[slot * 3 + 2];
+    const float f0x = a.w, f0y = b.x, f0z = b.y, f1x = b.z, f1y = b.w, f1z = c.x;
+    const float f2x = hx - a.x, f2y = hy - a.y, f2z = hz - a.z;
+    const float d00 = dot3(f0x, f0y, f0z, f0x, f0y, f0z);
+    const float d01 = dot3(f0x, f0y, f0z, f1x, f1y, f1z);
+    const float d11 = dot3(f1x, f1y, f1z, f1x, f1y, f1z);
+    const float d20 = dot3(f2x, f2y, f2z, f0x, f0y, f0z);
+    const float d21 = dot3(f2x, f2y, f2z, f1x, f1y, f1z);
+    const float denom = d00 * d11 - d01 * d01;
+    const float w1 = (d11 * d20 - d01 * d21) / denom;
+    const float w2 = (d00 * d21 - d01 * d20) / denom;
+    const float w0 = 1.0f - w1 - w2;
+    const float4 g0 = attrs[slot * 4], g1 = attrs[slot * 4 + 1], g2 = attrs[slot * 4 + 2],
+                 g3 = attrs[slot * 4 + 3];
+    // n0 = g0.xyz, n1 = (g0.w, g1.x, g1.y), n2 = (g1.z, g1.w, g2.x)
+    const float inx = (g0.x * w0 + g0.w * w1) + g1.z * w2;
+    const float iny = (g0.y * w0 + g1.x * w1) + g1.w * w2;
+    const float inz = (g0.z * w0 + g1.y * w1) + g2.x * w2;
+    // uv0 = (g2.y, g2.z), uv1 = (g2.w, g3.x), uv2 = (g3.y, g3.z)
+    uvx = (g2.y * w0 + g2.w * w1) + g3.y * w2;
+    uvy = (g2.z * w0 + g3.x * w1) + g3.z * w2;
+    nx = -inx;
+    ny = -iny;
+    nz = -inz;
+    normalize3(nx, ny, nz);
+}
+
+// sphereIntersect (meshEngine.cpp:182-194): float dots, float rad*rad, double discriminant
+__device__ __forceinline__ float sphere_hit(float ox, float oy, float oz, float dx, float dy, float dz,
+                                            const SphereDev &s) {
+    const float opx = s.cx - ox, opy = s.cy - oy, opz = s.cz - oz;
+    const double b = (double)dot3(opx, opy, opz, dx, dy, dz);
+    double det = b * b - (double)dot3(opx, opy, opz, opx, opy, opz) + (double)s.rad2;
+    if (det < 0) return 0.f;
+    det = sqrt(det);
+    double t = b - det;
+    if (t > 1e-4) return (float)t;
+    t = b + det;
+    if (t > 1e-4) return (float)t;
+    return 0.f;
+}
+
+struct CastResult {
+    float nearest;     // INFINITY on a miss
+    float nx, ny, nz;  // pHitNormal
+    float cr, cg, cb;  // pHitColour
+    float uvx, uvy;
+    float tri_t;
+    int slot;          // leaf-order slot of the BVH hit, -1 if none
+    bool material;
+};
+
+// MeshEngine::RayCast (meshEngine.cpp:239-509)
+template <bool COUNT>
+__device__ __forceinline__ void ray_cast(const SceneDev &sc, float ox, float oy, float oz, float dx,
+                                         float dy, float dz, uint2 *stk, CastResult &r, Cnt &cnt) {
+    float best;
+    int slot;
+    bvh_nearest<COUNT>(sc, ox, oy, oz, dx, dy, dz, stk, best, slot, cnt);
+    r.nearest = kInf;
+    r.nx = r.ny = r.nz = 0.f;
+    r.cr = r.cg = r.cb = 0.f;
+    r.uvx = r.uvy = 0.f;
+    r.tri_t = best;
+    r.slot = slot;
+    r.material = false;
+    if (slot >= 0) {
+        r.nearest = best;
+        const float hx = ox + dx * best, hy = oy + dy * best, hz = oz + dz * best;  // bvh.cpp:140
+        tri_shading_normal(sc, slot, hx, hy, hz, r.nx, r.ny, r.nz, r.uvx, r.uvy);
+        r.material = true;  // hitMeshIndex = 0 (meshEngine.cpp:370), never reset
+    }
+    const uint32_t ns = sc.nspheres;
+    for (uint32_t i = 0; i < ns; ++i) {
+        const SphereDev s = sc.spheres[i];
+        const float th = sphere_hit(ox, oy, oz, dx, dy, dz, s);
+        if (th > 0.f && th < r.nearest) {
+            r.nearest = th;
+            if (s.flags & 1u) {
+                r.cr = s.colr;
+                r.cg = s.colg;
+                r.cb = s.colb;
+            }
+            float px = ox + (dx * th) - s.ncx, py = oy + (dy * th) - s.ncy, pz = oz + (dz * th) - s.ncz;
+            normalize3(px, py, pz);
+            r.nx = px * s.nsign;
+            r.ny = py * s.nsign;
+            r.nz = pz * s.nsign;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// one iteration of Radiance's bounce loop (pathtracer.cpp:34-197)
+// ---------------------------------------------------------------------------
+struct Path {
+    float ox, oy, oz, dx, dy, dz;
+    float tr, tg, tb;      // accumRadiance (rgb)
+    float ar, ag, ab, aw;  // accumColour
+    uint32_t depth, dest;
+    Rng rng;
+};
+
+struct StepFlags {
+    bool was_ray, tri_hit, continues;
+};
+
+// returns true if the path continues with a new ray in P, false if accumColour is final
+template <bool COUNT>
+__device__ __forceinline__ bool path_step(const SceneDev &sc, float r2scale, Path &P, uint2 *stk,
+                                          StepFlags &fl, Cnt &cnt) {
+    CastResult c;
+    ray_cast<COUNT>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, stk, c, cnt);
+    fl.tri_hit = c.slot >= 0;
+    fl.continues = false;
+    if (!(c.nearest < kInf)) return false;  // pathtracer.cpp:36-41
+    P.ar = P.ar + P.tr * c.cr;              // :43 (w term adds 0)
+    P.ag = P.ag + P.tg * c.cg;
+    P.ab = P.ab + P.tb * c.cb;
+    if (P.depth == 0) P.aw = c.nearest;                                   // :44-47
+    if (sqrtf(dot3(c.cr, c.cg, c.cb, c.cr, c.cg, c.cb)) > 1.f) return false;  // :52
+    P.depth++;
+    if (P.depth > 5) {  // :56 — the draw happens only past depth 5
+        const double rr = rng_u01(P.rng);
+        if (rr > (double)0.95f || P.depth > 1000) return false;
+    }
+    // hit location and back-off along the incoming ray (:108,163,189)
+    const float lx = P.ox + (P.dx * c.nearest), ly = P.oy + (P.dy * c.nearest), lz = P.oz + (P.dz * c.nearest);
+    const float sx = lx - P.dx * 0.001f, sy = ly - P.dy * 0.001f, sz = lz - P.dz * 0.001f;
+    float ndx, ndy, ndz;
+    bool specular = false;
+    if (c.material) specular = rng_u01(P.rng) >= 0.96;  // :98
+    if (specular) {
+        (void)rng_next(P.rng);
+        (void)rng_next(P.rng);
+        (void)rng_next(P.rng);  // unused noise, :101-103
+        const float k = dot3(c.nx, c.ny, c.nz, P.dx, P.dy, P.dz);
+        ndx = P.dx - c.nx * 2.f * k;
+        ndy = P.dy - c.ny * 2.f * k;
+        ndz = P.dz - c.nz * 2.f * k;
+        normalize3(ndx, ndy, ndz);
+    } else {
+        float r2s, cs, sn, q;
+        if (c.material) {  // :151-165 (throughput *= white albedo: exact no-op)
+            const float r1 = (float)(6.283185307179586 * rng_u01(P.rng));
+            const float r2 = (float)((double)r2scale * rng_u01(P.rng));
+            r2s = sqrtf(r2);
+            cs = (float)cos((double)r1);
+            sn = (float)sin((double)r1);
+            q = sqrtf(1.0f - r2);
+        } else {  // :166-196 — nearest hit is a sphere and the BVH hit nothing
+            const double r1 = 6.283185307179586 * rng_u01(P.rng);
+            const double r2 = (double)r2scale * rng_u01(P.rng);
+            r2s = (float)sqrt(r2);
+            (void)rng_next(P.rng);
+            (void)rng_next(P.rng);
+            (void)rng_next(P.rng);  // :173-175
+            cs = (float)cos(r1);
+            sn = (float)sin(r1);
+            q = (float)sqrt(1.0 - r2);
+        }
+        const bool facing = dot3(c.nx, c.ny, c.nz, P.dx, P.dy, P.dz) < 0.f;
+        const float wx = facing ? c.nx : c.nx * -1.f, wy = facing ? c.ny : c.ny * -1.f,
+                    wz = facing ? c.nz : c.nz * -1.f;
+        const bool use_y = (double)fabsf(wx) > .1;
+        const float ax = use_y ? 0.f : 1.f, ay = use_y ? 1.f : 0.f, az = 0.f;
+        float ux, uy, uz, vx, vy, vz;
+        cross3(ax, ay, az, wx, wy, wz, ux, uy, uz);
+        normalize3(ux, uy, uz);
+        cross3(wx, wy, wz, ux, uy, uz, vx, vy, vz);
+        ndx = (ux * cs * r2s + vx * sn * r2s) + wx * q;
+        ndy = (uy * cs * r2s + vy * sn * r2s) + wy * q;
+        ndz = (uz * cs * r2s + vz * sn * r2s) + wz * q;
+        normalize3(ndx, ndy, ndz);
+    }
+    P.ox = sx;
+    P.oy = sy;
+    P.oz = sz;
+    P.dx = ndx;
+    P.dy = ndy;
+    P.dz = ndz;
+    // An all-NaN direction (r2 > 1, pathtracer.cpp:156-162) misses the BVH and
+    // every sphere in RayCast, so Radiance returns accumColour: end the path here.
+    if ((ndx != ndx) && (ndy != ndy) && (ndz != ndz)) return false;
+    fl.continues = finite3(ndx, ndy, ndz);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// path queue (SoA of float4 planes, 16 sub-queues)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void path_store(const QueueDev &q, uint32_t idx, const Path &P) {
+    float4 *pl = (float4 *)q.planes;
+    const size_t cap = q.capacity;
+    pl[idx] = make_float4(P.ox, P.oy, P.oz, P.dx);
+    pl[cap + idx] = make_float4(P.dy, P.dz, P.tr, P.tg);
+    pl[2 * cap + idx] = make_float4(P.tb, P.ar, P.ag, P.ab);
+    pl[3 * cap + idx] = make_float4(P.aw, __uint_as_float(P.depth), __uint_as_float(P.dest), 0.f);
+    pl[4 * cap + idx] = make_float4(__uint_as_float((uint32_t)P.rng.s0), __uint_as_float((uint32_t)(P.rng.s0 >> 32)),
+                                    __uint_as_float((uint32_t)P.rng.s1), __uint_as_float((uint32_t)(P.rng.s1 >> 32)));
+    pl[5 * cap + idx] = make_float4(__uint_as_float((uint32_t)P.rng.s2), __uint_as_float((uint32_t)(P.rng.s2 >> 32)),
+                                    __uint_as_float((uint32_t)P.rng.s3), __uint_as_float((uint32_t)(P.rng.s3 >> 32)));
+}
+
+__device__ __forceinline__ void path_load(const QueueDev &q, uint32_t idx, Path &P) {
+    const float4 *pl = (const float4 *)q.planes;
+    const size_t cap = q.capacity;
+    const float4 a = pl[idx], b = pl[cap + idx], c = pl[2 * cap + idx], d = pl[3 * cap + idx],
+                 e = pl[4 * cap + idx], f = pl[5 * cap + idx];
+    P.ox = a.x, P.oy = a.y, P.oz = a.z, P.dx = a.w;
+    P.dy = b.x, P.dz = b.y, P.tr = b.z, P.tg = b.w;
+    P.tb = c.x, P.ar = c.y, P.ag = c.z, P.ab = c.w;
+    P.aw = d.x, P.depth = __float_as_uint(d.y), P.dest = __float_as_uint(d.z);
+    P.rng.s0 = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
+    P.rng.s1 = (uint64_t)__float_as_uint(e.z) | ((uint64_t)__float_as_uint(e.w) << 32);
+    P.rng.s2 = (uint64_t)__float_as_uint(f.x) | ((uint64_t)__float_as_uint(f.y) << 32);
+    P.rng.s3 = (uint64_t)__float_as_uint(f.z) | ((uint64_t)__float_as_uint(f.w) << 32);
+}
+
+// wave ballot + prefix popcount compaction, one atomic per wave
+__device__ __forceinline__ void queue_append(const QueueDev &q, uint32_t sub, bool alive, const Path &P) {
+    const unsigned long long m = __ballot(alive);
+    if (m == 0) return;
+    const uint32_t n = (uint32_t)__popcll(m);
+    const uint32_t lane = lane_index();
+    uint32_t base = 0;
+    if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(&q.counts[sub * 32], n);
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (alive) path_store(q, sub * q.sub_capacity + base + rank, P);
+}
+
+__device__ __forceinline__ void tally_add(Tally &tl, const StepFlags &fl, bool ran, uint32_t stage_depth0) {
+    // stage 0 = steps taken at depth 0, stage 1 = bounce steps
+    const unsigned long long r0 = __ballot(ran && fl.was_ray && stage_depth0);
+    const unsigned long long r1 = __ballot(ran && fl.was_ray && !stage_depth0);
+    const unsigned long long h0 = __ballot(ran && fl.tri_hit && fl.was_ray && stage_depth0);
+    const unsigned long long h1 = __ballot(ran && fl.tri_hit && fl.was_ray && !stage_depth0);
+    const unsigned long long c0 = __ballot(ran && fl.continues && stage_depth0);
+    const unsigned long long c1 = __ballot(ran && fl.continues && !stage_depth0);
+    tl.rays[0] += (uint32_t)__popcll(r0);
+    tl.rays[1] += (uint32_t)__popcll(r1);
+    tl.hits[0] += (uint32_t)__popcll(h0);
+    tl.hits[1] += (uint32_t)__popcll(h1);
+    tl.cont[0] += (uint32_t)__popcll(c0);
+    tl.cont[1] += (uint32_t)__popcll(c1);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void tally_flush(DevCounters *ctr, const Tally &tl, const Cnt &c0, const Cnt &c1) {
+    uint32_t i0 = 0, t0 = 0, i1 = 0, t1 = 0;
+    if (COUNT) {
+        i0 = wave_sum(c0.inner);
+        t0 = wave_sum(c0.tris);
+        i1 = wave_sum(c1.inner);
+        t1 = wave_sum(c1.tris);
+    }
+    if (lane_index() == 0) {
+        for (int s = 0; s < 2; ++s) {
+            if (tl.rays[s]) atomicAdd(&ctr->stage[s].rays, (unsigned long long)tl.rays[s]);
+            if (tl.hits[s]) atomicAdd(&ctr->stage[s].tri_hits, (unsigned long long)tl.hits[s]);
+            if (tl.cont[s]) atomicAdd(&ctr->stage[s].continued, (unsigned long long)tl.cont[s]);
+        }
+        if (COUNT) {
+            if (i0) atomicAdd(&ctr->stage[0].inner_visits, (unsigned long long)i0);
+            if (t0) atomicAdd(&ctr->stage[0].tri_tests, (unsigned long long)t0);
+            if (i1) atomicAdd(&ctr->stage[1].inner_visits, (unsigned long long)i1);
+            if (t1) atomicAdd(&ctr->stage[1].tri_tests, (unsigned long long)t1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// ray generation (pathtracer.cpp:251-280); p = global pixel index, k = linear sample index
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void primary_ray(const FrameDev &fr, uint32_t p, uint32_t k, Rng &rng, float &dx,
+                                            float &dy, float &dz) {
+    rng_init(rng, fr.seed, p, k);
+    const float jx = rng_jitter(rng);  // :251
+    const float jy = rng_jitter(rng);  // :252
+    const uint32_t s = k / fr.quarter;
+    const float sx = (float)(s >> 1), sy = (float)(s & 1u);
+    const float fx = (float)(p % fr.width) + (sx * 0.5f - 0.5f) + jx;
+    const float fy = (float)(p / fr.width) + (sy * 0.5f - 0.5f) + jy;
+    const float hx = (float)((((double)fx - 0.25) / (double)fr.width) - 0.5);
+    const float hy = (float)((((double)fy - 0.25) / (double)fr.height) - 0.5);
+    const float gx = hx * fr.sensor_x, gy = -(hy * fr.sensor_y), gz = -fr.film_dist;
+    // cameraTransform * gridPane, GLM order (m0*x + m1*y) + (m2*z + m3*w), m3.xyz = 0, w = 1
+    float rx = (fr.m[0] * gx + fr.m[3] * gy) + (fr.m[6] * gz + 0.0f);
+    float ry = (fr.m[1] * gx + fr.m[4] * gy) + (fr.m[7] * gz + 0.0f);
+    float rz = (fr.m[2] * gx + fr.m[5] * gy) + (fr.m[8] * gz + 0.0f);
+    normalize3(rx, ry, rz);
+    dx = rx, dy = ry, dz = rz;
+}
+
+// local pixel index (rank-local packed rows) -> global pixel index
+__device__ __forceinline__ uint32_t global_pixel(const FrameDev &fr, uint32_t lp) {
+    const uint32_t lrow = lp / fr.width, x = lp - lrow * fr.width;
+    if (fr.world <= 1) return lp;
+    const uint32_t ls = lrow / fr.stripe_rows, r = lrow - ls * fr.stripe_rows;
+    const uint32_t grow = (ls * fr.world + fr.rank) * fr.stripe_rows + r;
+    return grow * fr.width + x;
+}
+
+// block-sized work item -> (sample plane j, first slot), XCD-aware:
+// items i and i+8 land on one XCD (round-robin block placement) and get neighbouring tiles
+__device__ __forceinline__ void item_to_tile(uint32_t item, uint32_t tiles8, uint32_t &j, uint32_t &tile) {
+    const uint32_t xcd = item & 7u, r = item >> 3, per = tiles8 >> 3;
+    j = r / per;
+    tile = xcd * per + (r - j * per);
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void k_trace(SceneDev sc, const float *__restrict__ o, const float *__restrict__ d, uint32_t n,
+                        int32_t *__restrict__ tri_id, float *__restrict__ t, DevCounters *ctr) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    Cnt cnt = {0, 0}, none = {0, 0};
+    Tally tl = {{0, 0}, {0, 0}, {0, 0}};
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        if (i < n) {
+            float best;
+            int slot;
+            bvh_nearest<COUNT>(sc, o[i * 3], o[i * 3 + 1], o[i * 3 + 2], d[i * 3], d[i * 3 + 1], d[i * 3 + 2], stk,
+                               best, slot, cnt);
+            tri_id[i] = slot >= 0 ? (int32_t)__float_as_uint(tris[slot * 3 + 2].y) : -1;
+            t[i] = best;
+        }
+    }
+    if (COUNT && ctr) tally_flush<true>(ctr, tl, cnt, none);
+}
+
+__global__ void k_raycast(SceneDev sc, const float *__restrict__ o, const float *__restrict__ d, uint32_t n,
+                          float4 *__restrict__ out) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    Cnt cnt = {0, 0};
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        if (i >= n) continue;
+        const float ox = o[i * 3], oy = o[i * 3 + 1], oz = o[i * 3 + 2];
+        const float dx = d[i * 3], dy = d[i * 3 + 1], dz = d[i * 3 + 2];
+        CastResult c;
+        ray_cast<false>(sc, ox, oy, oz, dx, dy, dz, stk, c, cnt);
+        const int32_t id = c.slot >= 0 ? (int32_t)__float_as_uint(tris[c.slot * 3 + 2].y) : -1;
+        const uint32_t flags = ((c.nearest < kInf) ? 1u : 0u) | (c.material ? 2u : 0u);
+        // vmx_rayhit: location[3], distance | normal[3], tri_id | uv[2], tri_t, flags | colour[3], pad
+        out[(size_t)i * 4] = make_float4(ox + (dx * c.nearest), oy + (dy * c.nearest), oz + (dz * c.nearest), c.nearest);
+        out[(size_t)i * 4 + 1] = make_float4(c.nx, c.ny, c.nz, __int_as_float(id));
+        out[(size_t)i * 4 + 2] = make_float4(c.uvx, c.uvy, c.tri_t, __uint_as_float(flags));
+        out[(size_t)i * 4 + 3] = make_float4(c.cr, c.cg, c.cb, 0.f);
+    }
+}
+
+__global__ void k_primary_ids(SceneDev sc, FrameDev fr, uint32_t k, int32_t *__restrict__ tri_id,
+                              float *__restrict__ t) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    const uint32_t npix = fr.width * fr.height;
+    Cnt cnt = {0, 0};
+    for (uint32_t base = blockIdx.x * blockDim.x; base < npix; base += gridDim.x * blockDim.x) {
+        const uint32_t p = base + threadIdx.x;
+        if (p >= npix) continue;
+        Rng rng;
+        float dx, dy, dz;
+        primary_ray(fr, p, k, rng, dx, dy, dz);
+        float best;
+        int slot;
+        bvh_nearest<false>(sc, fr.px, fr.py, fr.pz, dx, dy, dz, stk, best, slot, cnt);
+        tri_id[p] = slot >= 0 ? (int32_t)__float_as_uint(tris[slot * 3 + 2].y) : -1;
+        t[p] = best;
+    }
+}
+
+__global__ void k_init_pixels(PixelStateDev px, uint32_t npix) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    ((float4 *)px.accum)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    px.count[i] = 0;
+    px.cursor[i] = 0;
+}
+
+__global__ void k_zero_u32(unsigned int *p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+// raygen + RayCast + first Radiance step; LOOP: follow every path to its end
+template <bool COUNT, bool LOOP>
+__global__ void k_primary(SceneDev sc, FrameDev fr, const unsigned int *__restrict__ active, uint32_t n_active,
+                          uint32_t n_pad, uint32_t samples, PixelStateDev px, QueueDev qout,
+                          float4 *__restrict__ rad, DevCounters *ctr) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    const uint32_t tiles = (n_pad + blockDim.x - 1) / blockDim.x;
+    const uint32_t tiles8 = (tiles + 7u) & ~7u;
+    const uint32_t items = tiles8 * samples;
+    Cnt c0 = {0, 0}, c1 = {0, 0};
+    Tally tl = {{0, 0}, {0, 0}, {0, 0}};
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        uint32_t j, tile;
+        item_to_tile(item, tiles8, j, tile);
+        const uint32_t slot = tile * blockDim.x + threadIdx.x;
+        bool run = slot < n_active;
+        Path P;
+        uint32_t lp = 0;
+        if (run) {
+            lp = active[slot];
+            const uint32_t k = px.cursor[lp] + j;
+            run = k < fr.kmax;
+            if (run) {
+                const uint32_t p = global_pixel(fr, lp);
+                primary_ray(fr, p, k, P.rng, P.dx, P.dy, P.dz);
+                P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz;
+                P.tr = P.tg = P.tb = 1.f;
+                P.ar = P.ag = P.ab = 0.f;
+                P.aw = -100.f;  // pathtracer.cpp:29
+                P.depth = 0;
+                P.dest = j * n_pad + slot;
+            }
+        }
+        StepFlags fl = {false, false, false};
+        bool alive = false;
+        if (run) {
+            fl.was_ray = true;
+            alive = path_step<COUNT>(sc, fr.r2scale, P, stk, fl, c0);
+        }
+        tally_add(tl, fl, run, 1u);
+        if (LOOP) {
+            while (__any(alive)) {
+                StepFlags f2 = {false, false, false};
+                bool still = false;
+                if (alive) {
+                    f2.was_ray = finite3(P.dx, P.dy, P.dz);
+                    still = path_step<COUNT>(sc, fr.r2scale, P, stk, f2, c1);
+                }
+                tally_add(tl, f2, alive, 0u);
+                alive = still;
+            }
+            if (run) rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
+        } else {
+            if (run && !alive) rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
+            queue_append(qout, item % kSubQueues, alive, P);
+        }
+    }
+    tally_flush<COUNT>(ctr, tl, c0, c1);
+}
+
+// explicit camera rays for vmx_radiance: path i keyed (seed, i, 0), two jitter draws skipped
+__global__ void k_radiance_init(const float *__restrict__ o, const float *__restrict__ d, uint32_t n,
+                                uint64_t seed, QueueDev qout) {
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const bool run = i < n;
+        Path P;
+        if (run) {
+            rng_init(P.rng, seed, i, 0);
+            (void)rng_next(P.rng);
+            (void)rng_next(P.rng);
+            P.ox = o[i * 3], P.oy = o[i * 3 + 1], P.oz = o[i * 3 + 2];
+            P.dx = d[i * 3], P.dy = d[i * 3 + 1], P.dz = d[i * 3 + 2];
+            P.tr = P.tg = P.tb = 1.f;
+            P.ar = P.ag = P.ab = 0.f;
+            P.aw = -100.f;
+            P.depth = 0;
+            P.dest = i;
+        }
+        queue_append(qout, (base / blockDim.x) % kSubQueues, run, P);
+    }
+}
+
+// one Radiance step (LOOP: all remaining steps) for every queued path
+template <bool COUNT, bool LOOP>
+__global__ void k_bounce(SceneDev sc, float r2scale, QueueDev qin, uint32_t max_chunks, QueueDev qout,
+                         float4 *__restrict__ rad, DevCounters *ctr) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    const uint32_t items = max_chunks * kSubQueues;
+    Cnt c0 = {0, 0}, c1 = {0, 0};
+    Tally tl = {{0, 0}, {0, 0}, {0, 0}};
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
+        const uint32_t count = qin.counts[sub * 32];
+        const uint32_t pos = chunk * blockDim.x + threadIdx.x;
+        const bool run = pos < count;
+        Path P;
+        StepFlags fl = {false, false, false};
+        bool alive = false;
+        uint32_t depth0 = 0;
+        if (run) {
+            path_load(qin, sub * qin.sub_capacity + pos, P);
+            depth0 = P.depth == 0 ? 1u : 0u;
+            fl.was_ray = depth0 ? true : finite3(P.dx, P.dy, P.dz);
+            alive = depth0 ? path_step<COUNT>(sc, r2scale, P, stk, fl, c0)
+                           : path_step<COUNT>(sc, r2scale, P, stk, fl, c1);
+        }
+        tally_add(tl, fl, run, depth0);
+        if (LOOP) {
+            while (__any(alive)) {
+                StepFlags f2 = {false, false, false};
+                bool still = false;
+                if (alive) {
+                    f2.was_ray = finite3(P.dx, P.dy, P.dz);
+                    still = path_step<COUNT>(sc, r2scale, P, stk, f2, c1);
+                }
+                tally_add(tl, f2, alive, 0u);
+                alive = still;
+            }
+            if (run) rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
+        } else {
+            if (run && !alive) rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
+            queue_append(qout, sub, alive, P);
+        }
+    }
+    tally_flush<COUNT>(ctr, tl, c0, c1);
+}
+
+// per-pixel accumulation in sample order + early stop + pixel write (pathtracer.cpp:282-324)
+__global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, uint32_t n_active,
+                          uint32_t n_pad, uint32_t samples, const float4 *__restrict__ rad, PixelStateDev px,
+                          unsigned int *__restrict__ next_active, unsigned int *next_count,
+                          float *__restrict__ out, DevCounters *ctr) {
+    __shared__ unsigned int s_keep, s_base, s_taken, s_disc, s_done;
+    if (threadIdx.x == 0) s_keep = 0, s_taken = 0, s_disc = 0, s_done = 0;
+    __syncthreads();
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    uint32_t lp = 0, taken = 0, disc = 0, done = 0;
+    if (slot < n_active) {
+        lp = active[slot];
+        float4 acc = ((float4 *)px.accum)[lp];
+        uint32_t n = px.count[lp];
+        const uint32_t cursor = px.cursor[lp];
+        uint32_t next = cursor + samples;
+        for (uint32_t j = 0; j < samples; ++j) {
+            const uint32_t k = cursor + j;
+            if (k >= fr.kmax) break;
+            const float4 s = rad[(size_t)j * n_pad + slot];
+            ++n;  // :249
+            acc.x = acc.x + s.x;  // :283
+            acc.y = acc.y + s.y;
+            acc.z = acc.z + s.z;
+            ++taken;
+            if (fr.early_stop && n > fr.nmin) {  // n > sqrt(spp), :292
+                const float fn = (float)n, fn1 = (float)(n + 1);
+                const float ex = acc.x / fn - (acc.x + s.x) / fn1;
+                const float ey = acc.y / fn - (acc.y + s.y) / fn1;
+                const float ez = acc.z / fn - (acc.z + s.z) / fn1;
+                if (fabsf(sqrtf(dot3(ex, ey, ez, ex, ey, ez))) < 0.00001f) {
+                    next = (k / fr.quarter + 1u) * fr.quarter;  // break the innermost loop only
+                    const uint32_t last = cursor + samples < fr.kmax ? cursor + samples : fr.kmax;
+                    disc = last - (k + 1);
+                    break;
+                }
+            }
+        }
+        if (next >= fr.kmax) {
+            const float fn = (float)n;  // accum / nTotalSamples (uint -> float)
+            float *o5 = out + (size_t)lp * 5;
+            o5[0] = fmaxf(fminf(acc.x / fn, 1.f), 0.f);
+            o5[1] = fmaxf(fminf(acc.y / fn, 1.f), 0.f);
+            o5[2] = fmaxf(fminf(acc.z / fn, 1.f), 0.f);
+            o5[3] = 1.f;
+            o5[4] = fn;
+            done = 1;
+        } else {
+            keep = true;
+        }
+        ((float4 *)px.accum)[lp] = acc;
+        px.count[lp] = n;
+        px.cursor[lp] = next;
+    }
+    // block-aggregated append to the next active list
+    uint32_t my = 0;
+    if (keep) my = atomicAdd(&s_keep, 1u);
+    if (taken) atomicAdd(&s_taken, taken);
+    if (disc) atomicAdd(&s_disc, disc);
+    if (done) atomicAdd(&s_done, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_base = s_keep ? atomicAdd(next_count, s_keep) : 0u;
+        if (s_taken) atomicAdd(&ctr->samples, (unsigned long long)s_taken);
+        if (s_disc) atomicAdd(&ctr->discarded, (unsigned long long)s_disc);
+        if (s_done) atomicAdd(&ctr->pixels_done, (unsigned long long)s_done);
+    }
+    __syncthreads();
+    if (keep) next_active[s_base + my] = lp;
+}
+
+__global__ void k_assemble(const float *__restrict__ gathered, uint64_t rank_stride, uint32_t width,
+                           uint32_t height, uint32_t stripe_rows, uint32_t world, float *__restrict__ frame) {
+    const uint64_t total = (uint64_t)width * height * 5;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(i / ((uint64_t)width * 5));
+        const uint64_t in_row = i - (uint64_t)row * width * 5;
+        const uint32_t gs = row / stripe_rows, r = row - gs * stripe_rows;
+        const uint32_t rank = gs % world, ls = gs / world;
+        const uint64_t lrow = (uint64_t)ls * stripe_rows + r;
+        frame[i] = gathered[rank * rank_stride + lrow * width * 5 + in_row];
+    }
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+int launch_trace(const SceneDev &sc, const float *o, const float *d, uint32_t n, int32_t *tri_id, float *t,
+                 DevCounters *counters, bool count, LaunchCfg cfg, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (count)
+        hipLaunchKernelGGL(k_trace<true>, dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, sc, o, d, n, tri_id, t,
+                           counters);
+    else
+        hipLaunchKernelGGL(k_trace<false>, dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, s, sc, o, d, n, tri_id, t,
+                           counters);
+    return launch_status();
+}
+
+int launch_raycast(const SceneDev &sc, const float *o, const float *d, uint32_t n, void *out, LaunchCfg cfg,
+                   void *stream) {
+    hipLaunchKernelGGL(k_raycast, dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, (hipStream_t)stream, sc, o, d, n,
+                       (float4 *)out);
+    return launch_status();
+}
+
+int launch_primary_ids(const SceneDev &sc, const FrameDev &fr, uint32_t k, int32_t *tri_id, float *t, LaunchCfg cfg,
+                       void *stream) {
+    hipLaunchKernelGGL(k_primary_ids, dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, (hipStream_t)stream, sc, fr, k,
+                       tri_id, t);
+    return launch_status();
+}
+
+int launch_init_pixels(PixelStateDev px, uint32_t npix, void *stream) {
+    hipLaunchKernelGGL(k_init_pixels, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream, px, npix);
+    return launch_status();
+}
+
+int launch_zero_u32(unsigned int *p, uint32_t n, void *stream) {
+    hipLaunchKernelGGL(k_zero_u32, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, n);
+    return launch_status();
+}
+
+int launch_primary(const SceneDev &sc, const FrameDev &fr, const unsigned int *active, uint32_t n_active,
+                   uint32_t samples, PixelStateDev px, QueueDev qout, void *rad, DevCounters *counters, bool count,
+                   bool loop_to_end, LaunchCfg cfg, void *stream) {
+    const uint32_t n_pad = (n_active + 63u) & ~63u;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(cfg.grid), b(cfg.block);
+#define VMX_GO(C, L)                                                                                              \
+    hipLaunchKernelGGL((k_primary<C, L>), g, b, cfg.lds_bytes, s, sc, fr, active, n_active, n_pad, samples, px, \
+                       qout, (float4 *)rad, counters)
+    if (count) {
+        if (loop_to_end) VMX_GO(true, true);
+        else VMX_GO(true, false);
+    } else {
+        if (loop_to_end) VMX_GO(false, true);
+        else VMX_GO(false, false);
+    }
+#undef VMX_GO
+    return launch_status();
+}
+
+int launch_radiance_init(const float *o, const float *d, uint32_t n, uint64_t seed, QueueDev qout, void *stream) {
+    uint32_t grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_radiance_init, dim3(grid), dim3(256), 0, (hipStream_t)stream, o, d, n, seed, qout);
+    return launch_status();
+}
+
+int launch_bounce(const SceneDev &sc, float r2scale, QueueDev qin, uint32_t max_chunks, QueueDev qout, void *rad,
+                  DevCounters *counters, bool count, bool loop_to_end, bool, LaunchCfg cfg, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(cfg.grid), b(cfg.block);
+#define VMX_GO(C, L)                                                                                       \
+    hipLaunchKernelGGL((k_bounce<C, L>), g, b, cfg.lds_bytes, s, sc, r2scale, qin, max_chunks, qout,      \
+                       (float4 *)rad, counters)
+    if (count) {
+        if (loop_to_end) VMX_GO(true, true);
+        else VMX_GO(true, false);
+    } else {
+        if (loop_to_end) VMX_GO(false, true);
+        else VMX_GO(false, false);
+    }
+#undef VMX_GO
+    return launch_status();
+}
+
+int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,
+                   const void *rad, PixelStateDev px, unsigned int *next_active, unsigned int *next_count,
+                   float *out_rgbaz, DevCounters *counters, void *stream) {
+    const uint32_t n_pad = (n_active + 63u) & ~63u;
+    hipLaunchKernelGGL(k_resolve, dim3((n_active + 255) / 256), dim3(256), 0, (hipStream_t)stream, fr, active,
+                       n_active, n_pad, samples, (const float4 *)rad, px, next_active, next_count, out_rgbaz,
+                       counters);
+    return launch_status();
+}
+
+int launch_assemble(const float *gathered, uint64_t rank_stride_floats, uint32_t width, uint32_t height,
+                    uint32_t stripe_rows, uint32_t world, float *frame, void *stream) {
+    hipLaunchKernelGGL(k_assemble, dim3(2048), dim3(256), 0, (hipStream_t)stream, gathered, rank_stride_floats, width,
+                       height, stripe_rows, world, frame);
+    return launch_status();
+}
+
+int query_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *primary_blocks, int *bounce_blocks) {
+    int a = 0, b = 0;
+    hipError_t e;
+    if (count) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_primary<true, false>, (int)block, lds_bytes);
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_bounce<true, false>, (int)block, lds_bytes);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_primary<false, false>, (int)block, lds_bytes);
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_bounce<false, false>, (int)block, lds_bytes);
+    }
+    if (primary_blocks) *primary_blocks = a;
+    if (bounce_blocks) *bounce_blocks = b;
+    return (int)e;
+}
+
+}  // namespace vmx

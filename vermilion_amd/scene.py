@@ -1,0 +1,197 @@
+"""Thin object wrapper over the C ABI: one `Scene` = one `vmx_scene*`.
+
+numpy arrays in, numpy arrays out; all compute happens in libvermilion_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f32(a, shape_last=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape_last is not None and (a.ndim == 0 or a.shape[-1] != shape_last):
+        a = a.reshape(-1, shape_last)
+    return a
+
+
+def make_camera(position, rotation_deg, width, height, spp, back_distance=6.0, back_size=(3.6, 2.4)):
+    """cameraSettings subset (core/camera/camera.h:32-47); defaults follow
+    RenderEngine::CreateInternalDefaultCamera (core/engines/renderEngine.cpp:135-139)."""
+    c = L.CameraDesc()
+    c.position[:] = [float(v) for v in position]
+    c.rotation_deg[:] = [float(v) for v in rotation_deg]
+    c.back_distance = float(back_distance)
+    c.back_size[:] = [float(back_size[0]), float(back_size[1])]
+    c.image_res[:] = [int(width), int(height)]
+    c.rays_per_pixel = int(spp)
+    return c
+
+
+def make_opts(seed=1, early_stop=True, sampling=L.VMX_SAMPLING_PARITY, rank=0, world=1, stripe_rows=16,
+              samples_per_batch=0, collect_counters=False, pipeline=0, max_paths=0, tail_threshold=0):
+    o = L.Opts()
+    o.seed = int(seed)
+    o.early_stop = 1 if early_stop else 0
+    o.sampling = int(sampling)
+    o.rank, o.world, o.stripe_rows = int(rank), int(world), int(stripe_rows)
+    o.samples_per_batch = int(samples_per_batch)
+    o.collect_counters = 1 if collect_counters else 0
+    o.reserved[0] = int(pipeline)      # 0 wavefront, 1 every lane follows its path to the end
+    o.reserved[1] = int(max_paths)     # paths in flight per pass (0 -> 16M)
+    o.reserved[2] = int(tail_threshold)
+    return o
+
+
+def spheres_array(spheres):
+    """list of dicts/tuples -> ctypes array of vmx_sphere"""
+    arr = (L.Sphere * len(spheres))()
+    for i, s in enumerate(spheres):
+        arr[i].centre[:] = [float(v) for v in s["centre"]]
+        arr[i].radius = float(s["radius"])
+        arr[i].colour[:] = [float(v) for v in s.get("colour", (0, 0, 0))]
+        arr[i].flags = L.VMX_SPHERE_EMIT if s.get("emit", False) else 0
+        arr[i].normal_centre[:] = [float(v) for v in s.get("normal_centre", s["centre"])]
+        arr[i].normal_sign = float(s.get("normal_sign", 1.0))
+    return arr
+
+
+def default_spheres():
+    n = C.c_uint32(0)
+    p = L.lib().vmx_default_spheres(C.byref(n))
+    out = (L.Sphere * n.value)()
+    for i in range(n.value):
+        C.memmove(C.byref(out[i]), C.byref(p[i]), C.sizeof(L.Sphere))
+    return out
+
+
+class Scene:
+    """Device-resident scene: replaces MeshEngine::createBVH + BVH for the HIP path."""
+
+    def __init__(self, pos, nrm, uv=None, spheres=None, leaf_size=4, device=0):
+        pos = _f32(pos).reshape(-1, 9)
+        nrm = _f32(nrm).reshape(-1, 9)
+        if pos.shape != nrm.shape:
+            raise ValueError("pos and nrm must both be [ntris, 9]")
+        uvp = None
+        if uv is not None:
+            uv = _f32(uv).reshape(-1, 6)
+            uvp = uv.ctypes.data
+        self._spheres = spheres
+        sp, nsp = (None, 0) if spheres is None else (C.addressof(spheres), len(spheres))
+        h = C.c_void_p()
+        L.check(L.lib().vmx_scene_create(pos.ctypes.data, nrm.ctypes.data, uvp, pos.shape[0], sp, nsp,
+                                         int(leaf_size), int(device), C.byref(h)))
+        self._h = h
+        self.ntris = pos.shape[0]
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().vmx_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- introspection ----------------------------------------------------
+    def describe(self):
+        d = L.SceneDesc()
+        L.check(L.lib().vmx_scene_describe(self._h, C.byref(d)))
+        return {k: getattr(d, k) for k, _ in d._fields_ if k != "pad"}
+
+    def bvh(self):
+        n = self.describe()["n_nodes"]
+        start = np.zeros(n, np.uint32)
+        nprims = np.zeros(n, np.uint32)
+        roff = np.zeros(n, np.uint32)
+        bbox = np.zeros((n, 6), np.float32)
+        order = np.zeros(self.ntris, np.uint32)
+        L.check(L.lib().vmx_scene_bvh(self._h, start.ctypes.data, nprims.ctypes.data, roff.ctypes.data,
+                                      bbox.ctypes.data, order.ctypes.data))
+        return {"start": start, "nprims": nprims, "right_offset": roff, "bbox": bbox, "prim_order": order}
+
+    # -- parity hooks -------------------------------------------------------
+    def trace(self, origin, direction):
+        o, d = _f32(origin, 3), _f32(direction, 3)
+        n = o.shape[0]
+        tri = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        L.check(L.lib().vmx_trace(self._h, o.ctypes.data, d.ctypes.data, n, tri.ctypes.data, t.ctypes.data))
+        return tri, t
+
+    def raycast(self, origin, direction):
+        o, d = _f32(origin, 3), _f32(direction, 3)
+        n = o.shape[0]
+        out = np.zeros(n, dtype=RAYHIT_DTYPE)
+        L.check(L.lib().vmx_raycast(self._h, o.ctypes.data, d.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def primary_ids(self, cam, opts, k=0):
+        n = cam.image_res[0] * cam.image_res[1]
+        tri = np.empty(n, np.int32)
+        t = np.empty(n, np.float32)
+        L.check(L.lib().vmx_primary_ids(self._h, C.byref(cam), C.byref(opts), int(k), tri.ctypes.data,
+                                        t.ctypes.data))
+        return tri, t
+
+    def radiance(self, origin, direction, opts):
+        o, d = _f32(origin, 3), _f32(direction, 3)
+        n = o.shape[0]
+        out = np.empty((n, 4), np.float32)
+        st = L.Stats()
+        L.check(L.lib().vmx_radiance(self._h, o.ctypes.data, d.ctypes.data, n, C.byref(opts), out.ctypes.data,
+                                     C.byref(st)))
+        return out, st.as_dict()
+
+    # -- render ---------------------------------------------------------------
+    def render(self, cam, opts):
+        """PathTracer::Render into a host array [local_rows, W, 5] (RGBAZ)."""
+        rows = local_rows(cam.image_res[1], opts.stripe_rows, opts.rank, opts.world)
+        out = np.empty((rows, cam.image_res[0], 5), np.float32)
+        st = L.Stats()
+        L.check(L.lib().vmx_render(self._h, C.byref(cam), C.byref(opts), out.ctypes.data, C.byref(st)))
+        return out, st.as_dict()
+
+    def render_device(self, cam, opts, d_out_ptr, stream_ptr=None):
+        """Same, into device memory (e.g. a torch tensor's data_ptr()) on `stream_ptr`."""
+        st = L.Stats()
+        L.check(L.lib().vmx_render_device(self._h, C.byref(cam), C.byref(opts), C.c_void_p(d_out_ptr),
+                                          C.c_void_p(stream_ptr or 0), C.byref(st)))
+        return st.as_dict()
+
+
+RAYHIT_DTYPE = np.dtype([
+    ("location", np.float32, 3), ("distance", np.float32), ("normal", np.float32, 3), ("tri_id", np.int32),
+    ("uv", np.float32, 2), ("tri_t", np.float32), ("flags", np.uint32), ("colour", np.float32, 3),
+    ("pad", np.uint32),
+])
+assert RAYHIT_DTYPE.itemsize == 64
+
+
+def local_rows(height, stripe_rows, rank, world):
+    r = C.c_uint32(0)
+    L.check(L.lib().vmx_local_rows(int(height), int(stripe_rows), int(rank), int(world), C.byref(r)))
+    return r.value
+
+
+def local_row_indices(height, stripe_rows, rank, world):
+    """global row index of every local row of (rank, world) — pure host logic"""
+    stripe_rows = stripe_rows or 16
+    if world <= 1:
+        return np.arange(height)
+    rows = []
+    n_stripes = (height + stripe_rows - 1) // stripe_rows
+    for s in range(rank, n_stripes, world):
+        rows.extend(range(s * stripe_rows, min((s + 1) * stripe_rows, height)))
+    return np.asarray(rows, dtype=np.int64)
