@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json metric).
+
+One "step" = one full frame of the Sponza stand-in (256,152 triangles) at
+1920x1080, 256 spp, rendered by the HIP path tracer (PathTracer::Render
+equivalent), inputs resident in HBM before the timed region.  With N > 1 the
+frame is sharded into interleaved 16-row stripes (one process per GPU), the
+packed stripes are gathered to rank 0 over RCCL and de-interleaved there; the
+gather and assembly are inside the timed step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first: one HIP runtime per process)
+import torch.distributed as dist  # noqa: E402
+
+import vermilion_amd as va  # noqa: E402
+from vermilion_amd import dist as vdist  # noqa: E402
+from vermilion_amd import scenes  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes(stage):
+    """B_ray = 64*N_inner + 48*N_tri + 48 + 64*[tri hit] + 96*[path continues]"""
+    return (64 * stage["inner_visits"] + 48 * stage["tri_tests"] + 48 * stage["rays"] + 64 * stage["tri_hits"]
+            + 96 * stage["continued"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--scene", default="sponza260k")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    gen, camf = scenes.SCENES[args.scene]
+    pos, nrm, uv = gen()
+    sc = va.Scene(pos, nrm, uv, device=local_rank)
+    desc = sc.describe()
+    c = camf()
+    W, H, spp = args.width, args.height, args.spp
+    cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
+    stripe = 16
+    rows = va.local_rows(H, stripe, rank, world)
+    local = torch.empty((rows, W, 5), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step(early_stop=False, counters=False):
+        opts = va.make_opts(seed=args.seed, early_stop=early_stop, sampling=va.VMX_SAMPLING_PARITY, rank=rank,
+                            world=world, stripe_rows=stripe, collect_counters=counters)
+        st = sc.render_device(cam, opts, local.data_ptr(), stream)
+        frame = vdist.gather_frame(local, W, H, stripe, rank, world, dst=0)
+        return st, frame
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def timed(k, **kw):
+        sync()
+        t0 = time.perf_counter()
+        stats = [step(**kw)[0] for _ in range(k)]
+        sync()
+        dt = time.perf_counter() - t0
+        rays = float(sum(s["rays_primary"] + s["rays_secondary"] for s in stats))
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r = torch.tensor([rays], dtype=torch.float64, device=dev)
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            dt, rays = float(t.item()), float(r.item())
+        return dt, rays, stats
+
+    # counters pass (instrumented kernels, untimed): algorithmic bytes of this exact frame
+    cst, _ = step(counters=True)
+    for _ in range(args.warmup):
+        step()
+    dt, rays, stats = timed(args.steps)
+    ms_per_step = dt / args.steps * 1e3
+    value = rays / dt / 1e6
+
+    # reference-faithful frame (early stop on, pathtracer.cpp:290-311), same frame otherwise
+    step(early_stop=True)
+    es_k = max(1, min(args.steps, 3))
+    es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
+
+    if rank == 0:
+        prim_ms = sum(s["primary"]["ms"] for s in stats)
+        prim_launches = sum(s["primary"]["launches"] for s in stats)
+        bytes_per_launch = alg_bytes(cst["primary"]) / max(cst["primary"]["launches"], 1)
+        avg_ms = prim_ms / max(prim_launches, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_primary_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        total_rays_frame = cst["rays_primary"] + cst["rays_secondary"]
+        out = {
+            "metric": "Mrays/sec (primary+secondary), 1920x1080 Sponza",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} ({desc['ntris']} tris, procedural Sponza stand-in) {W}x{H} {spp}spp, "
+                            "reference sampling (r2=10U), fixed spp (early stop off), reference sphere table",
+                "rays_per_frame": int(rays / args.steps),
+                "parallelism": f"stripes{stripe}x{world}" if world > 1 else "single",
+                "bvh": {"nodes": desc["n_nodes"], "max_depth": desc["max_depth"], "leaf_size": desc["leaf_size"]},
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_primary (raygen + BVH/sphere RayCast + Radiance step, depth 0)",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "alg_bytes_per_launch": int(bytes_per_launch),
+                "avg_launch_ms": round(avg_ms, 4),
+                "launches_per_step": prim_launches // max(args.steps, 1),
+                "alg_bytes_per_ray": round(alg_bytes(cst["primary"]) / max(cst["primary"]["rays"], 1), 1),
+                "inner_visits_per_ray": round(cst["primary"]["inner_visits"] / max(cst["primary"]["rays"], 1), 2),
+                "tri_tests_per_ray": round(cst["primary"]["tri_tests"] / max(cst["primary"]["rays"], 1), 2),
+            },
+            "stage_ms_per_step": {
+                "primary": round(prim_ms / args.steps, 3),
+                "bounce": round(sum(s["bounce"]["ms"] for s in stats) / args.steps, 3),
+                "device_total": round(sum(s["ms_device"] for s in stats) / args.steps, 3),
+            },
+            "whole_frame_alg_GBs": round((alg_bytes(cst["primary"]) + alg_bytes(cst["bounce"])) / (ms_per_step * 1e-3) / 1e9, 1)
+            if world == 1 else None,
+            "reference_frame": {
+                "what": "same frame with the reference's early-stop rule on (pathtracer.cpp:290-311)",
+                "ms_per_frame": round(es_dt / es_k * 1e3, 3),
+                "Mrays_per_s": round(es_rays / es_dt / 1e6, 2),
+                "rays_per_frame": int(es_rays / es_k),
+                "passes": es_stats[0]["passes"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pos, nrm, uv, c, W, H, args.cpu_spp, args.seed)
+        print(json.dumps(out), flush=True)
+    sc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pos, nrm, uv, c, W, H, spp, seed):
+    """The CPU oracle (the reference's algorithm restated, built with the reference's
+    -Ofast -fopenmp flags) timed on this box's host cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    osc = O.OracleScene(pos, nrm, uv, fast=True)
+    cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
+    opts = va.make_opts(seed=seed, early_stop=False)
+    warm = va.make_camera(c["position"], c["rotation_deg"], W // 8, H // 8, 4, back_size=(3.6, 3.6 * H / W))
+    osc.render(warm, opts)
+    t0 = time.perf_counter()
+    _, st = osc.render(cam, opts)
+    dt = time.perf_counter() - t0
+    rays = st["rays_primary"] + st["rays_secondary"]
+    return {
+        "value": round(rays / dt / 1e6, 3),
+        "unit": "Mrays/s",
+        "cores": O.max_threads(),
+        "kind": "port",
+        "sample": f"same scene/camera/seed at {W}x{H}, {spp} spp fixed ({rays} rays, {dt:.1f} s), "
+                  "OpenMP schedule(dynamic,1) over pixels, g++ -Ofast, per-pixel stderr progress suppressed",
+    }
+
+
+if __name__ == "__main__":
+    main()

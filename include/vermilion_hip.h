@@ -163,7 +163,8 @@ const vmx_sphere *vmx_default_spheres(uint32_t *count);
  * bvh.cpp:155-279) for the device: `pos`/`nrm` are [ntris*9] floats
  * (v0,v1,v2 / n0,n1,n2 per triangle), `uv` is [ntris*6] or NULL (zeros),
  * in createBVH push order — that order defines triangle IDs.
- * spheres == NULL && nspheres == 0 selects vmx_default_spheres().
+ * spheres == NULL && nspheres == 0 selects vmx_default_spheres(); a non-NULL
+ * pointer with nspheres == 0 means no spheres at all.
  * leaf_size 0 -> 4 (bvh.h:29).  The BVH is built on the host with the
  * reference's topology, flattened to 2-wide records and uploaded to `device`.
  */

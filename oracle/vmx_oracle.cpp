@@ -489,7 +489,13 @@ struct PathStats {
     Counters cnt;
 };
 
-inline bool finite3(V3 v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); }
+/* bit test, so that the -Ofast (finite-math-only) baseline build cannot fold it away */
+inline bool finite1(float f) {
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    return (b & 0x7F800000u) != 0x7F800000u;
+}
+inline bool finite3(V3 v) { return finite1(v.x) && finite1(v.y) && finite1(v.z); }
 
 /* Radiance, pathtracer.cpp:21-198.  No texture is bound in any configuration
  * (pathtracer.cpp:63-66 not taken), so sampleColour is (1,1,1,1) (:75-79). */

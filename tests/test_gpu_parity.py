@@ -1,0 +1,284 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs (bit-exact: integer IDs, float bit patterns,
+whole frames) and against the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import vermilion_amd as va
+from vermilion_amd import scenes
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def rand_rays(n, seed, lo=(-1500, 5, -900), hi=(1500, 950, 900)):
+    r = np.random.RandomState(seed)
+    o = r.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = r.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+class Pair:
+    def __init__(self, pos, nrm, uv=None, spheres=None, leaf_size=4):
+        self.gpu = va.Scene(pos, nrm, uv, spheres=spheres, leaf_size=leaf_size)
+        self.cpu = O.OracleScene(pos, nrm, uv, spheres=spheres, leaf_size=leaf_size)
+
+    def close(self):
+        self.gpu.close()
+        self.cpu.close()
+
+
+@pytest.fixture(scope="module", params=["cornell8", "lattice", "bunny70k", "sponza260k"])
+def pair(request):
+    gen, camf = scenes.SCENES[request.param]
+    p = Pair(*gen())
+    p.name, p.camf = request.param, camf
+    yield p
+    p.close()
+
+
+def assert_raycast_equal(a, b):
+    for f in a.dtype.names:
+        if f == "pad":
+            continue
+        x, y = a[f], b[f]
+        same = (bits(x) == bits(y)) if x.dtype == np.float32 else (x == y)
+        assert np.all(same), f"raycast field {f}: {int((~same).sum())} mismatches"
+
+
+def test_bvh_topology_equals_reference_restatement(pair):
+    g, c = pair.gpu.bvh(), pair.cpu.bvh()
+    for k in g:
+        assert np.array_equal(g[k], c[k]), k
+    d, od = pair.gpu.describe(), pair.cpu.describe()
+    assert (d["n_nodes"], d["n_leaves"], d["max_depth"]) == (od["n_nodes"], od["n_leaves"], od["max_depth"])
+    assert d["stack_entries"] >= d["max_depth"] + 1
+
+
+def test_trace_ids_and_distances_bit_exact(pair):
+    o, d = rand_rays(300000 if pair.name != "cornell8" else 100000, 3)
+    tri, t = pair.gpu.trace(o, d)
+    rtri, rt = pair.cpu.trace(o, d)
+    assert (tri >= 0).sum() > 1000
+    assert np.array_equal(tri, rtri)
+    assert np.array_equal(bits(t), bits(rt))
+
+
+def test_raycast_full_tuple_bit_exact(pair):
+    o, d = rand_rays(100000, 4)
+    assert_raycast_equal(pair.gpu.raycast(o, d), pair.cpu.raycast(o, d))
+
+
+def test_primary_hit_triangle_ids_bit_exact(pair):
+    """BASELINE config 2: primary-hit triangle IDs exact vs the CPU"""
+    c = pair.camf()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 512, 512, 64)
+    opts = va.make_opts(seed=12)
+    for k in (0, 37):
+        tri, t = pair.gpu.primary_ids(cam, opts, k)
+        o, d = O.primary_rays(cam, opts, k)
+        rtri, rt = pair.cpu.trace(o, d)
+        assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+        assert (tri >= 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("sampling", [0, 1])
+def test_radiance_paths_bit_exact(pair, sampling):
+    c = pair.camf()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 256, 128, 16)
+    opts = va.make_opts(seed=5, sampling=sampling, collect_counters=True)
+    o, d = O.primary_rays(cam, opts, 1)
+    rad, st = pair.gpu.radiance(o, d, opts)
+    rrad, rst = pair.cpu.radiance(o, d, opts)
+    assert np.array_equal(bits(rad), bits(rrad))
+    assert st["rays_primary"] == rst["rays_primary"] == o.shape[0]
+    assert st["rays_secondary"] == rst["rays_secondary"]
+    assert st["primary"]["inner_visits"] + st["bounce"]["inner_visits"] == rst["primary"]["inner_visits"]
+    assert st["primary"]["tri_tests"] + st["bounce"]["tri_tests"] == rst["primary"]["tri_tests"]
+    assert st["primary"]["tri_hits"] + st["bounce"]["tri_hits"] == rst["primary"]["tri_hits"]
+
+
+@pytest.mark.parametrize("early_stop,sampling", [(1, 0), (0, 0), (1, 1), (0, 1)])
+def test_frame_bit_exact(pair, early_stop, sampling):
+    c = pair.camf()
+    W, H, spp = (160, 96, 16) if pair.name in ("bunny70k", "sponza260k") else (128, 128, 16)
+    if sampling == 1 and pair.name == "sponza260k":
+        W, H = 96, 64  # the oracle needs ~25 rays per sample here
+    cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
+    opts = va.make_opts(seed=9, early_stop=bool(early_stop), sampling=sampling)
+    img, st = pair.gpu.render(cam, opts)
+    ref, rst = pair.cpu.render(cam, opts)
+    assert img.shape == (H, W, 5)
+    assert np.array_equal(bits(img), bits(ref)), f"{int((bits(img) != bits(ref)).any(axis=2).sum())} pixels differ"
+    assert st["rays_primary"] == rst["rays_primary"] and st["rays_secondary"] == rst["rays_secondary"]
+    assert st["samples"] == rst["samples"] == int(img[:, :, 4].sum())
+    assert st["samples_discarded"] == 0
+
+
+@pytest.mark.parametrize("name", ["cornell8", "lattice"])
+def test_against_committed_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    with va.Scene(g["pos"], g["nrm"], g["uv"]) as sc:
+        tri, t = sc.trace(g["ray_o"], g["ray_d"])
+        assert np.array_equal(tri, g["trace_id"]) and np.array_equal(bits(t), bits(g["trace_t"]))
+        assert np.array_equal(sc.raycast(g["ray_o"], g["ray_d"]).view(np.uint32).reshape(-1, 16)[:, :15],
+                              g["raycast"][:, :15])
+        b = sc.bvh()
+        for k, v in b.items():
+            assert np.array_equal(v, g["bvh_" + k]), k
+        cp = g["cam"]
+        cam = va.make_camera(cp[:3], cp[3:6], int(cp[6]), int(cp[7]), int(cp[8]))
+        pid, pt = sc.primary_ids(cam, va.make_opts(seed=3), 0)
+        assert np.array_equal(pid, g["primary_id"]) and np.array_equal(bits(pt), bits(g["primary_t"]))
+        for sampling in (0, 1):
+            rad, _ = sc.radiance(g["primary_o"], g["primary_d"], va.make_opts(seed=3, sampling=sampling))
+            assert np.array_equal(bits(rad), bits(g[f"radiance_s{sampling}"]))
+            for es in (0, 1):
+                img, st = sc.render(cam, va.make_opts(seed=3, early_stop=bool(es), sampling=sampling))
+                assert np.array_equal(bits(img), bits(g[f"render_es{es}_s{sampling}"]))
+                assert [st["rays_primary"], st["rays_secondary"], st["samples"]] == g[f"rays_es{es}_s{sampling}"].tolist()
+
+
+# ---- edge cases ------------------------------------------------------------------
+def test_special_rays_nan_slabs_ties_and_degenerates():
+    """axis-parallel rays on slab planes (NaN products, bbox.cpp:70-83), shared-edge ties,
+    zero / NaN / inf directions, NaN origins"""
+    g = np.load(os.path.join(GOLD, "lattice.npz"))
+    o, d = g["ray_o"][:60], g["ray_d"][:60]
+    for gen in (scenes.cornell8, scenes.lattice):
+        p = Pair(*gen())
+        tri, t = p.gpu.trace(o, d)
+        rtri, rt = p.cpu.trace(o, d)
+        assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+        assert_raycast_equal(p.gpu.raycast(o, d), p.cpu.raycast(o, d))
+        p.close()
+    # a grid of axis-parallel rays whose origins sit exactly on box planes of an axis-aligned scene
+    pos, nrm, uv = scenes.cornell8()
+    p = Pair(pos, nrm, uv)
+    xs = np.float32([-600, -250, 0, 150, 600, -250.00002, 149.99998])
+    oo, dd = [], []
+    for x in xs:
+        for y in np.float32([1, 400, 900, 200]):
+            for dvec in ((0, 0, -1), (0, 0, 1), (0, -1, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0)):
+                oo.append((x, y, 300.0)), dd.append(dvec)
+                oo.append((x, y, 0.0)), dd.append(dvec)
+    tri, t = p.gpu.trace(oo, dd)
+    rtri, rt = p.cpu.trace(oo, dd)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    assert_raycast_equal(p.gpu.raycast(oo, dd), p.cpu.raycast(oo, dd))
+    p.close()
+
+
+@pytest.mark.parametrize("ntris,leaf", [(1, 4), (3, 4), (5, 1), (8, 2), (8, 8), (200, 1), (200, 7), (200, 31)])
+def test_tiny_scenes_and_leaf_sizes(ntris, leaf):
+    pos, nrm, uv = scenes.lattice() if ntris > 8 else scenes.cornell8()
+    p = Pair(pos[:ntris], nrm[:ntris], uv[:ntris], leaf_size=leaf)
+    g, c = p.gpu.bvh(), p.cpu.bvh()
+    for k in g:
+        assert np.array_equal(g[k], c[k]), k
+    o, d = rand_rays(20000, ntris + leaf, lo=(-900, 5, -700), hi=(900, 900, 1500))
+    tri, t = p.gpu.trace(o, d)
+    rtri, rt = p.cpu.trace(o, d)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    c0 = scenes.lattice_camera()
+    cam = va.make_camera(c0["position"], c0["rotation_deg"], 40, 24, 8)
+    img, _ = p.gpu.render(cam, va.make_opts(seed=2))
+    ref, _ = p.cpu.render(cam, va.make_opts(seed=2))
+    assert np.array_equal(bits(img), bits(ref))
+    p.close()
+
+
+def test_custom_sphere_tables():
+    pos, nrm, uv = scenes.cornell8()
+    area_light = va.spheres_array([
+        dict(centre=(0, 700, 300), radius=200, colour=(1.5, 1.2, 0.9), emit=True),
+        dict(centre=(300, 500, 400), radius=60, colour=(0.4, 0.1, 0.1), emit=True),  # weak emitter: path continues
+        dict(centre=(0, -5e7, 0), radius=5e7), dict(centre=(0, 5e7 + 1000, 0), radius=5e7),
+        dict(centre=(-5e7 + 2000, 0, 0), radius=5e7, normal_sign=-1),
+        dict(centre=(5e7 - 2000, 0, 0), radius=5e7, normal_sign=-1),
+        dict(centre=(0, 0, -5e7 + 2000), radius=5e7, normal_sign=-1), dict(centre=(0, 0, 5e7 - 2000), radius=5e7)])
+    none = (va._lib.Sphere * 1)()
+    for table, n in ((area_light, 8), (none, 0)):
+        sub = (va._lib.Sphere * n).from_buffer(table) if n else (va._lib.Sphere * 0)()
+        p = Pair(pos, nrm, uv, spheres=sub)
+        assert p.gpu.describe()["nspheres"] == n
+        o, d = rand_rays(50000, 8, lo=(-500, 5, -700), hi=(500, 890, 1500))
+        assert_raycast_equal(p.gpu.raycast(o, d), p.cpu.raycast(o, d))
+        c0 = scenes.cornell_camera()
+        cam = va.make_camera(c0["position"], c0["rotation_deg"], 96, 64, 32)
+        for sampling in (0, 1):
+            opts = va.make_opts(seed=21, sampling=sampling)
+            img, st = p.gpu.render(cam, opts)
+            ref, rst = p.cpu.render(cam, opts)
+            assert np.array_equal(bits(img), bits(ref))
+            assert st["rays_secondary"] == rst["rays_secondary"]
+        if n:
+            assert img[:, :, :3].mean() > 0.01  # the area light actually lights the set
+        p.close()
+
+
+@pytest.mark.parametrize("W,H,spp", [(1, 1, 4), (7, 3, 4), (37, 23, 12), (65, 9, 100), (8, 8, 7)])
+def test_ragged_image_sizes_and_spp(W, H, spp):
+    pos, nrm, uv = scenes.lattice()
+    p = Pair(pos, nrm, uv)
+    c0 = scenes.lattice_camera()
+    cam = va.make_camera(c0["position"], c0["rotation_deg"], W, H, spp)
+    for es in (0, 1):
+        opts = va.make_opts(seed=W * 100 + H, early_stop=bool(es))
+        img, st = p.gpu.render(cam, opts)
+        ref, rst = p.cpu.render(cam, opts)
+        assert np.array_equal(bits(img), bits(ref))
+        assert st["samples"] == rst["samples"]
+    p.close()
+
+
+def test_error_behaviour_on_device():
+    pos, nrm, uv = scenes.cornell8()
+    with va.Scene(pos, nrm, uv) as sc:
+        c0 = scenes.cornell_camera()
+        with pytest.raises(va.VmxError) as e:
+            sc.render(va.make_camera(c0["position"], c0["rotation_deg"], 8, 8, 3), va.make_opts())
+        assert e.value.code == va._lib.VMX_ERR_INVALID  # spp/4 == 0
+        with pytest.raises(va.VmxError):
+            sc.render(va.make_camera(c0["position"], c0["rotation_deg"], 0, 8, 16), va.make_opts())
+        with pytest.raises(va.VmxError):
+            sc.render(va.make_camera(c0["position"], c0["rotation_deg"], 8, 8, 16), va.make_opts(rank=2, world=2))
+        tri, t = sc.trace(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+        assert tri.shape == (0,)
+    bad = pos.copy()
+    bad[0, 0] = np.nan
+    with pytest.raises(va.VmxError):
+        va.Scene(bad, nrm, uv)
+    with pytest.raises(va.VmxError) as e:
+        va.Scene(pos, nrm, uv, device=99)
+    assert e.value.code == va._lib.VMX_ERR_NO_DEVICE
+    with pytest.raises(va.VmxError):
+        va.Scene(pos, nrm, uv, leaf_size=64)
+
+
+def test_plugin_surface_end_to_end():
+    """main.cpp:58-95 call order through the mirrored seam"""
+    pos, nrm, uv = scenes.cornell8()
+    mEng = va.MeshEngine()
+    integrator = va.PathTracer(seed=4)
+    rEng = va.RenderEngine(mEng)
+    rEng.assignIntegrator(integrator)
+    mEng.loadTriangles(pos, nrm, uv)
+    c0 = scenes.cornell_camera()
+    rEng.mCameras.append(va.Camera(va.cameraSettings(imageResX=64, imageResY=48, raysPerPixel=16,
+                                                     position=va.float3(*c0["position"]),
+                                                     rotation=va.float3(*c0["rotation_deg"]))))
+    rEng.draw()
+    cam = rEng.mCameras[0]
+    ref, _ = O.OracleScene(pos, nrm, uv).render(cam._desc(), va.make_opts(seed=4))
+    assert np.array_equal(bits(cam.image()), bits(ref))
+    hit, mat, loc, nrm_, dist, uvv, col = mEng.RayCast([[0, 420, 1900]], [[0, 0, -1]])
+    assert hit[0] and mat[0] and abs(dist[0] - 1900.0) < 1e-3

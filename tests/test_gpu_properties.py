@@ -1,0 +1,107 @@
+"""Size-independent properties at BASELINE.json's full sizes, where the CPU
+oracle is too slow to run the whole frame: determinism, invariance of the
+frame to every scheduling parameter (pass size, pipeline form, tail threshold,
+stripe sharding), and sample-count invariants."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import vermilion_amd as va
+from vermilion_amd import dist as vdist
+from vermilion_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def sponza():
+    sc = va.Scene(*scenes.sponza260k())
+    yield sc
+    sc.close()
+
+
+def sponza_cam(W, H, spp):
+    c = scenes.sponza_camera()
+    return va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
+
+
+def test_full_size_frame_invariants(sponza):
+    """1920x1080 Sponza stand-in (BASELINE config 4 geometry) at 16 spp"""
+    cam = sponza_cam(1920, 1080, 16)
+    a, sa = sponza.render(cam, va.make_opts(seed=1, early_stop=False))
+    assert np.all(a[:, :, 4] == 16.0) and np.all(a[:, :, 3] == 1.0)
+    assert sa["samples"] == 1920 * 1080 * 16 == sa["rays_primary"]
+    assert np.all(a[:, :, :3] >= 0) and np.all(a[:, :, :3] <= 1) and np.all(np.isfinite(a))
+    # scheduling must not change a single bit
+    for kw in (dict(samples_per_batch=3), dict(pipeline=1), dict(tail_threshold=1), dict(max_paths=1 << 20)):
+        b, sb = sponza.render(cam, va.make_opts(seed=1, early_stop=False, **kw))
+        assert np.array_equal(bits(a), bits(b)), kw
+        assert sb["rays_secondary"] == sa["rays_secondary"]
+    # early stop: the reference's sample-count pattern (one stratum at a time), same rays twice
+    e1, s1 = sponza.render(cam, va.make_opts(seed=1, early_stop=True))
+    e2, s2 = sponza.render(cam, va.make_opts(seed=1, early_stop=True, pipeline=1))
+    assert np.array_equal(bits(e1), bits(e2)) and s1["rays_primary"] == s2["rays_primary"]
+    assert set(np.unique(e1[:, :, 4])).issubset({7.0, 10.0, 13.0, 16.0})
+    dark = e1[:, :, :3].sum(-1) == 0
+    assert np.all(e1[:, :, 4][dark] == 7.0)
+    assert s1["samples"] == int(e1[:, :, 4].sum()) and s1["samples_discarded"] == 0
+    # oracle spot check on a crop of primary hits at full resolution
+    tri, t = sponza.primary_ids(cam, va.make_opts(seed=1), 5)
+    o, d = O.primary_rays(cam, va.make_opts(seed=1), 5)
+    sel = np.arange(0, 1920 * 1080, 97)
+    osc = O.OracleScene(*scenes.sponza260k())
+    rtri, rt = osc.trace(o[sel], d[sel])
+    assert np.array_equal(tri[sel], rtri) and np.array_equal(bits(t[sel]), bits(rt))
+
+
+@pytest.mark.parametrize("world,stripe", [(2, 16), (3, 7), (8, 16), (5, 64)])
+def test_sharded_frames_assemble_to_the_single_gpu_frame(sponza, world, stripe):
+    W, H = 320, 200
+    cam = sponza_cam(W, H, 16)
+    full, sf = sponza.render(cam, va.make_opts(seed=6))
+    parts, rays = [], 0
+    mrows = vdist.max_local_rows(H, stripe, world)
+    for r in range(world):
+        img, st = sponza.render(cam, va.make_opts(seed=6, rank=r, world=world, stripe_rows=stripe))
+        assert img.shape[0] == va.local_rows(H, stripe, r, world)
+        rays += st["rays_primary"] + st["rays_secondary"]
+        pad = np.zeros((mrows, W, 5), np.float32)
+        pad[:img.shape[0]] = img
+        parts.append(pad)
+    assert np.array_equal(bits(vdist.assemble_host(parts, W, H, stripe, world)), bits(full))
+    assert rays == sf["rays_primary"] + sf["rays_secondary"]
+
+
+def test_device_assemble_kernel(sponza):
+    import torch
+    W, H, stripe, world = 200, 131, 16, 4
+    cam = sponza_cam(W, H, 8)
+    full, _ = sponza.render(cam, va.make_opts(seed=3))
+    mrows = vdist.max_local_rows(H, stripe, world)
+    stride = mrows * W * 5
+    big = torch.zeros(world * stride, device="cuda")
+    for r in range(world):
+        rows = va.local_rows(H, stripe, r, world)
+        out = torch.empty((rows, W, 5), device="cuda")
+        sponza.render_device(cam, va.make_opts(seed=3, rank=r, world=world, stripe_rows=stripe), out.data_ptr())
+        big[r * stride:r * stride + out.numel()] = out.reshape(-1)
+    import ctypes as C
+    frame = torch.empty((H, W, 5), device="cuda")
+    va._lib.check(va._lib.lib().vmx_assemble_device(C.c_void_p(big.data_ptr()), stride, W, H, stripe, world,
+                                                    C.c_void_p(frame.data_ptr()), 0, None))
+    assert np.array_equal(bits(frame.cpu().numpy()), bits(full))
+
+
+def test_early_stop_and_fixed_spp_estimate_the_same_image(sponza):
+    """statistical: early stop changes per-pixel sample counts, not the expectation"""
+    cam = sponza_cam(480, 270, 64)
+    opts = dict(seed=2, sampling=va.VMX_SAMPLING_CORRECTED)
+    a, _ = sponza.render(cam, va.make_opts(early_stop=False, **opts))
+    b, sb = sponza.render(cam, va.make_opts(early_stop=True, **opts))
+    assert sb["samples"] <= 480 * 270 * 64
+    ma, mb = a[:, :, :3].mean(), b[:, :, :3].mean()
+    assert abs(ma - mb) <= 0.15 * max(ma, 1e-3) + 1e-3

@@ -1,0 +1,239 @@
+"""The CPU oracle against (a) the reference-run observations recorded in
+SURVEY.md, (b) hand-derived known answers, (c) its own committed golden
+fixtures.  The reference has no tests or golden vectors of its own
+and cannot be built here, so parity with the reference proper stays unpinned
+beyond (a)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import vermilion_amd as va
+from vermilion_amd import scenes
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    return O.OracleScene(*scenes.cornell8())
+
+
+def one(sc, o, d):
+    return sc.raycast(np.asarray([o], np.float32), np.asarray([d], np.float32))[0]
+
+
+# ---- (a) observations of the real reference recorded by the survey ------------
+def test_wall_sphere_cancellation_matches_survey_probe(cornell):
+    """a ray that should hit the ceiling sphere at ~499.9 returned 499.287"""
+    h = one(cornell, (0, 500, 1800), (0, 1, 0))
+    assert abs(float(h["distance"]) - 499.287) < 5e-4
+    assert h["tri_id"] == -1 and (h["flags"] & 1) and not (h["flags"] & 2)
+
+
+def test_light_leaks_through_nearer_wall_sphere(cornell):
+    """SURVEY A-2: light 2 (y=3300) colours a hit whose nearest surface is the ceiling"""
+    v = np.array([0.0, 3000.0, -3700.0])
+    h = one(cornell, (0, 300, 5000), v / np.linalg.norm(v))
+    assert np.allclose(h["colour"], 15.2) and float(h["location"][1]) < 1010.0
+
+
+def test_dark_pixels_take_seven_samples_at_16spp(cornell):
+    """SURVEY A-9 / App. B: 16 spp -> dark pixels take 7 samples, mean 7.02 on an 8-tri scene"""
+    c = scenes.cornell_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 64, 64, 16)
+    img, st = cornell.render(cam, va.make_opts(seed=2))
+    depth = img[:, :, 4]
+    dark = img[:, :, :3].sum(-1) == 0
+    assert dark.mean() > 0.9 and np.all(depth[dark] == 7.0)
+    assert 7.0 <= depth.mean() < 7.1
+    assert set(np.unique(depth)).issubset({7.0, 10.0, 13.0, 16.0})  # one stratum of 4 at a time
+    assert np.all(img[:, :, 3] == 1.0)
+
+
+def test_nan_direction_misses_everything(cornell):
+    """SURVEY A-1: a NaN direction misses the BVH and all spheres"""
+    h = one(cornell, (0, 100, 0), (np.nan, np.nan, np.nan))
+    assert not (h["flags"] & 1) and h["tri_id"] == -1 and np.isinf(h["distance"])
+
+
+def test_parity_sampling_rarely_returns_light(cornell):
+    """SURVEY A-1: with r2 = 10U only ~1 in 10 diffuse bounces continues; most paths are black"""
+    n = 20000
+    o = np.tile(np.float32([0, 420, 1900]), (n, 1))
+    d = np.tile(np.float32([0, -0.2, -1]) / np.linalg.norm([0, -0.2, -1]), (n, 1)).astype(np.float32)
+    rad, st = cornell.radiance(o, d, va.make_opts(seed=4))
+    frac = (rad[:, :3].sum(1) > 0).mean()
+    assert frac < 0.01
+    # continuing bounces ~ 0.04 + 0.96*0.1 of the material hits
+    assert 0.10 < st["rays_secondary"] / st["rays_primary"] < 0.20
+
+
+# ---- (b) hand-derived known answers ---------------------------------------------
+def test_moller_trumbore_known_answers():
+    pos = np.float32([[0, 0, 0, 4, 0, 0, 0, 4, 0]])
+    nrm = np.float32([[0, 0, 1] * 3])
+    sc = O.OracleScene(pos, nrm, spheres=(va._lib.Sphere * 1)())  # no usable sphere: radius 0
+    tri, t = sc.trace([[1, 1, 5], [1, 1, -5], [3, 3, 5], [1, 1, 5], [0, 0, 5]],
+                      [[0, 0, -1], [0, 0, 1], [0, 0, -1], [0, 0, 1], [0, 0, -1]])
+    assert tri.tolist() == [0, 0, -1, -1, 0]          # two-sided (A-11); u+v>1 misses; t>0 only; vertex hit
+    assert t[0] == 5.0 and t[1] == 5.0 and t[4] == 5.0
+    assert t[2] == np.float32(999999999.0)             # bvh.cpp:48
+    h = sc.raycast([[1, 1, 5]], [[0, 0, -1]])[0]
+    assert np.allclose(h["normal"], [0, 0, -1])        # interpolated normal is negated (A-12)
+    assert (h["flags"] & 3) == 3
+
+
+def test_first_tested_triangle_wins_ties():
+    """strict < at bvh.cpp:90: two coincident triangles -> the earlier leaf slot wins"""
+    pos = np.float32([[0, 0, 0, 4, 0, 0, 0, 4, 0], [0, 0, 0, 4, 0, 0, 0, 4, 0]])
+    nrm = np.float32([[0, 0, 1] * 3] * 2)
+    sc = O.OracleScene(pos, nrm)
+    tri, _ = sc.trace([[1, 1, 5]], [[0, 0, -1]])
+    order = sc.bvh()["prim_order"]
+    assert tri[0] == order[0]
+
+
+def test_bvh_topology_small():
+    pos, nrm, uv = scenes.cornell8()
+    sc = O.OracleScene(pos, nrm, uv)
+    b = sc.bvh()
+    assert sc.describe() == {"n_nodes": 5, "n_leaves": 3, "max_depth": 2}
+    assert b["right_offset"][0] != 0 and sorted(b["prim_order"].tolist()) == list(range(8))
+    # leaves partition the primitive range; every leaf has <= 4 prims (bvh.h:29)
+    leaves = b["right_offset"] == 0
+    assert b["nprims"][leaves].sum() == 8 and b["nprims"][leaves].max() <= 4
+    # 4 triangles or fewer: the root itself is a leaf
+    sc1 = O.OracleScene(pos[:3], nrm[:3])
+    assert sc1.describe()["n_nodes"] == 1
+    # node boxes bound their triangles
+    for i in np.nonzero(leaves)[0]:
+        ids = b["prim_order"][b["start"][i]:b["start"][i] + b["nprims"][i]]
+        p = pos[ids].reshape(-1, 3)
+        assert np.all(p.min(0) >= b["bbox"][i, :3]) and np.all(p.max(0) <= b["bbox"][i, 3:])
+
+
+def test_split_axis_quirk_compares_z_with_y_only():
+    """bbox.cpp:41-46: extent (10, 1, 5) picks z (5 > 1), not x"""
+    tris = []
+    for i in range(8):
+        x, z = 10.0 * i / 7, 5.0 * (i % 2)
+        tris.append([x, 0, z, x + .1, 0, z, x, .1, z])
+    pos = np.float32(tris)
+    nrm = np.float32([[0, 1, 0] * 3] * 8)
+    b = O.OracleScene(pos, nrm).bvh()
+    left = b["prim_order"][b["start"][1]:b["start"][1] + b["nprims"][1]]
+    assert sorted(left.tolist()) == [0, 2, 4, 6]       # split on z, although x is the widest axis
+
+
+def test_camera_matrix_and_forward_axis():
+    cam = va.make_camera((0, 0, 0), (0, 0, 0), 8, 8, 4)
+    assert np.array_equal(O.camera_matrix(cam), np.eye(3, dtype=np.float32))
+    o, d = O.primary_rays(va.make_camera((1, 2, 3), (0, 0, 0), 33, 17, 4), va.make_opts(seed=1), 0)
+    assert np.all(o == np.float32([1, 2, 3])) and np.all(d[:, 2] < -0.9)
+    assert np.allclose(np.linalg.norm(d, axis=1), 1, atol=1e-6)
+    # rotation (rx,ry,rz) degrees -> Ry(-ry) Rx(-rx) Rz(rz) (camera.cpp:43-47, pathtracer.cpp:219-221)
+    rx, ry, rz = 10.0, 35.0, -20.0
+    a, b, c = np.radians([-rx, -ry, rz])
+    Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+    Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+    Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+    M = O.camera_matrix(va.make_camera((0, 0, 0), (rx, ry, rz), 8, 8, 4)).T  # [row][col]
+    assert np.allclose(M, Ry @ Rx @ Rz, atol=2e-6)
+
+
+def test_pixel_footprint_and_film_geometry():
+    """jitter footprint [-0.75, 0.25) around the integer pixel coordinate"""
+    W, H = 16, 8
+    cam = va.make_camera((0, 0, 0), (0, 0, 0), W, H, 64, back_distance=6.0, back_size=(3.6, 2.4))
+    for k in (0, 17, 40, 63):
+        _, d = O.primary_rays(cam, va.make_opts(seed=k), k)
+        film = d / -d[:, 2:3] * 6.0
+        px = (film[:, 0] / 3.6 + 0.5) * W
+        py = (-film[:, 1] / 2.4 + 0.5) * H
+        ex, ey = px - np.arange(W * H) % W, py - np.arange(W * H) // W
+        s = k // 16
+        lox, loy = (s >> 1) * 0.5 - 0.75, (s & 1) * 0.5 - 0.75
+        assert np.all(ex >= lox - 1e-4) and np.all(ex < lox + 0.5 + 1e-4)
+        assert np.all(ey >= loy - 1e-4) and np.all(ey < loy + 0.5 + 1e-4)
+
+
+def test_rng_stream():
+    import ctypes as C
+    # splitmix64 known-answer (Vigna's reference implementation, seed 1234567)
+    st = C.c_uint64(1234567)
+    got = [O.lib().orc_splitmix64(C.byref(st)) for _ in range(3)]
+    assert got == [6457827717110365317, 3203168211198807973, 9817491932198370423]
+    a = O.stream(1, 2, 3, 64)
+    assert np.array_equal(a, O.stream(1, 2, 3, 64)) and len(set(a.tolist())) == 64
+    assert not np.array_equal(a, O.stream(1, 2, 4, 64)) and not np.array_equal(a, O.stream(1, 3, 3, 64))
+    big = np.concatenate([O.stream(9, p, 0, 256) for p in range(64)])
+    u = (big >> np.uint64(11)).astype(np.float64) * 2.0**-53
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+
+
+def test_early_stop_off_takes_every_sample_and_spp_rounds_down(cornell):
+    c = scenes.cornell_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 24, 16, 18)  # 18/4 = 4 -> 16 samples (A-17)
+    img, st = cornell.render(cam, va.make_opts(seed=1, early_stop=False))
+    assert np.all(img[:, :, 4] == 16.0) and st["samples"] == 24 * 16 * 16 == st["rays_primary"]
+
+
+def test_reference_rng_and_keyed_rng_agree_statistically():
+    """mt19937_64 (the reference's generator) vs the keyed xoshiro streams: same estimator"""
+    pos, nrm, uv = scenes.cornell8()
+    lights = va.spheres_array([
+        dict(centre=(0, 700, 300), radius=200, colour=(1.5, 1.2, 0.9), emit=True),
+        dict(centre=(0, -5e7, 0), radius=5e7), dict(centre=(0, 5e7 + 1000, 0), radius=5e7),
+        dict(centre=(-5e7 + 2000, 0, 0), radius=5e7, normal_sign=-1), dict(centre=(5e7 - 2000, 0, 0), radius=5e7, normal_sign=-1),
+        dict(centre=(0, 0, -5e7 + 2000), radius=5e7, normal_sign=-1), dict(centre=(0, 0, 5e7 - 2000), radius=5e7)])
+    sc = O.OracleScene(pos, nrm, uv, spheres=lights)
+    c = scenes.cornell_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 24, 24, 256)
+    opts = va.make_opts(seed=5, early_stop=False, sampling=va.VMX_SAMPLING_CORRECTED)
+    a, _ = sc.render(cam, opts, rng_mode=O.ORC_RNG_XOSHIRO_KEYED)
+    b, _ = sc.render(cam, opts, rng_mode=O.ORC_RNG_MT19937_64)
+    ma, mb = a[:, :, :3].mean(), b[:, :, :3].mean()
+    assert ma > 0.02 and abs(ma - mb) / ma < 0.05
+    l2 = np.sqrt(((a[:, :, :3] - b[:, :, :3]) ** 2).sum(-1)).mean()
+    assert l2 < 0.08  # per-pixel L2, Monte-Carlo noise at 256 spp
+
+
+# ---- (c) committed golden fixtures ---------------------------------------------------
+@pytest.mark.parametrize("name", ["cornell8", "lattice"])
+def test_oracle_reproduces_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sc = O.OracleScene(g["pos"], g["nrm"], g["uv"])
+    tri, t = sc.trace(g["ray_o"], g["ray_d"])
+    assert np.array_equal(tri, g["trace_id"]) and np.array_equal(bits(t), bits(g["trace_t"]))
+    assert np.array_equal(sc.raycast(g["ray_o"], g["ray_d"]).view(np.uint32).reshape(-1, 16), g["raycast"])
+    b = sc.bvh()
+    for k, v in b.items():
+        assert np.array_equal(v, g["bvh_" + k]), k
+    cp = g["cam"]
+    cam = va.make_camera(cp[:3], cp[3:6], int(cp[6]), int(cp[7]), int(cp[8]))
+    for sampling in (0, 1):
+        rad, _ = sc.radiance(g["primary_o"], g["primary_d"], va.make_opts(seed=3, sampling=sampling))
+        assert np.array_equal(bits(rad), bits(g[f"radiance_s{sampling}"]))
+        for es in (0, 1):
+            img, st = sc.render(cam, va.make_opts(seed=3, early_stop=bool(es), sampling=sampling))
+            assert np.array_equal(bits(img), bits(g[f"render_es{es}_s{sampling}"]))
+            assert [st["rays_primary"], st["rays_secondary"], st["samples"]] == g[f"rays_es{es}_s{sampling}"].tolist()
+    po, pd = O.primary_rays(cam, va.make_opts(seed=3), 0)
+    assert np.array_equal(bits(pd), bits(g["primary_d"]))
+    for i, (s, p, k) in enumerate(((0, 0, 0), (1, 2, 3), (2**63 + 5, 2**31, 255))):
+        assert np.array_equal(O.stream(s, p, k, 8), g["stream"][i])
+
+
+def test_mt_radiance_is_deterministic_per_seed(cornell):
+    g = np.load(os.path.join(GOLD, "cornell8.npz"))
+    o, d = g["primary_o"][:512], g["primary_d"][:512]
+    seeds = np.arange(512, dtype=np.uint64) + 100
+    a = cornell.radiance_mt(o, d, seeds)
+    assert np.array_equal(bits(a), bits(cornell.radiance_mt(o, d, seeds)))
+    assert np.all(a[:, 3] > 0)  # w = primary hit distance (pathtracer.cpp:44-47)

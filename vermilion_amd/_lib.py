@@ -149,6 +149,13 @@ SYMBOLS = {
 def load(path=None):
     """Load the HIP library and declare its prototypes.  Raises if it is absent."""
     path = path or LIB_PATH
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.
+    # If torch is importable, load it first so this library binds to the same
+    # runtime (two runtimes in one process cannot both open the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -474,8 +474,8 @@ int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32
     if (!out) return fail(VMX_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!pos || !nrm || ntris == 0) return fail(VMX_ERR_INVALID, "scene needs positions, normals, ntris > 0");
-    if ((spheres == nullptr) != (nspheres == 0))
-        return fail(VMX_ERR_INVALID, "spheres/nspheres mismatch (NULL,0 selects the reference table)");
+    if (spheres == nullptr && nspheres != 0)
+        return fail(VMX_ERR_INVALID, "spheres is NULL but nspheres > 0 (NULL,0 selects the reference table)");
     if (nspheres > kMaxSpheres) return fail(VMX_ERR_INVALID, "more than 16 spheres");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

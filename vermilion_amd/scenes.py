@@ -209,7 +209,7 @@ def sponza260k(seed=1):
         for i in range(60):
             y = 500.0 + 1.5 * (i % 20)
             x0 = -1400.0 + 46.6 * i
-            add(_box((x0, y + 60, zc - 3), (x0 + 900.0 if i % 3 == 0 else x0 + 44.0, y + 66, zc + 3)))
+            add(_box((x0, y + 60, zc - 3), (min(x0 + 900.0, 1450.0) if i % 3 == 0 else x0 + 44.0, y + 66, zc + 3)))
     P = np.concatenate([p[0].reshape(-1, 9) for p in parts])
     N = np.concatenate([p[1].reshape(-1, 9) for p in parts])
     T = np.concatenate([p[2].reshape(-1, 6) for p in parts])
@@ -228,7 +228,30 @@ def heightfield(n, extent=1600.0, height=120.0, y0=200.0):
         n, n))
 
 
+def lattice(n=10):
+    """2*n*n tilted quads' triangles whose coordinates are small integers (exact in
+    float32, no transcendental functions): identical on every machine, used for
+    the committed golden fixtures."""
+    P, N, T = [], [], []
+    for i in range(n):
+        for j in range(n):
+            x0, z0 = -900 + 180 * i, -700 + 140 * j
+            y0 = 40 + 7 * ((i * 3 + j * 5) % 11)
+            y1 = y0 + 9 * ((i + 2 * j) % 5)
+            a, b = (x0, y0, z0), (x0 + 150, y0, z0 + 10)
+            c, d = (x0 + 160, y1 + 30, z0 + 120), (x0 - 5, y1 + 25, z0 + 115)
+            nn = (0.0, 1.0, 0.0) if (i + j) % 2 else (0.6, 0.8, 0.0)
+            p, nq, t = _quad(a, b, c, d, nn)
+            P.append(p), N.append(nq), T.append(t)
+    return _finish(np.concatenate(P), np.concatenate(N), np.concatenate(T))
+
+
+def lattice_camera():
+    return dict(position=(0.0, 700.0, 1500.0), rotation_deg=(20.0, 0.0, 0.0))
+
+
 SCENES = {
+    "lattice": (lattice, lattice_camera),
     "cornell8": (cornell8, cornell_camera),
     "bunny70k": (bunny70k, bunny_camera),
     "sponza260k": (sponza260k, sponza_camera),
