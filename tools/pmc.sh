@@ -1,0 +1,15 @@
+#!/bin/bash
+# PMC passes for the bench command (run on the GPU box through gpurun).  One counter group per
+# rocprofv3 run (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2 — MI355X_MICROARCH.md).
+set -o pipefail
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+ARGS="${BENCH_ARGS:---steps 1 --warmup 0 --spp 64 --no-cpu-baseline}"
+TAG=${TAG:-r01}
+cd /tmp
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 280 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py $ARGS > $R/gpurun_out/pmc_${TAG}_$i.json 2> $R/gpurun_out/pmc_${TAG}_$i.err || { echo "pmc pass $i ($grp) failed"; tail -3 $R/gpurun_out/pmc_${TAG}_$i.err; }
+  echo "pass $i done: $grp"
+done

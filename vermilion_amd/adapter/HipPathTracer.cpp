@@ -1,0 +1,85 @@
+// HipPathTracer.cpp — see HipPathTracer.h.  Marshals the reference's objects
+// into the plain-C ABI of include/vermilion_hip.h; no rendering happens here.
+#include "HipPathTracer.h"
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace Vermilion {
+
+HipPathTracer::~HipPathTracer() { vmx_scene_destroy(mScene); }
+
+// Flatten MeshEngine::sceneMeshes exactly as MeshEngine::createBVH does
+// (core/engines/meshEngine.cpp:660-718): mesh-major, face-minor; that push
+// order defines the triangle IDs.  BVH internals are private (bvh.h:19-26),
+// so the library builds its own BVH with the same topology.
+bool HipPathTracer::upload(MeshEngine *mEng) {
+    std::vector<float> pos, nrm, uv;
+    size_t faces = 0;
+    for (aiMesh *mesh : mEng->sceneMeshes) faces += mesh->mNumFaces;
+    if (mScene && mUploadedFrom == mEng && mUploadedFaces == faces) return true;
+    pos.reserve(faces * 9), nrm.reserve(faces * 9), uv.reserve(faces * 6);
+    float lastUv[6] = {0, 0, 0, 0, 0, 0};  // createBVH leaves v*uv untouched for meshes without UVs
+    for (aiMesh *mesh : mEng->sceneMeshes) {
+        for (unsigned f = 0; f < mesh->mNumFaces; ++f) {
+            for (int c = 0; c < 3; ++c) {
+                const unsigned i = mesh->mFaces[f].mIndices[c];
+                pos.push_back(mesh->mVertices[i].x), pos.push_back(mesh->mVertices[i].y), pos.push_back(mesh->mVertices[i].z);
+                nrm.push_back(mesh->mNormals[i].x), nrm.push_back(mesh->mNormals[i].y), nrm.push_back(mesh->mNormals[i].z);
+                if (mesh->HasTextureCoords(0)) {
+                    lastUv[c * 2] = mesh->mTextureCoords[0][i].x;
+                    lastUv[c * 2 + 1] = mesh->mTextureCoords[0][i].y;
+                }
+            }
+            uv.insert(uv.end(), lastUv, lastUv + 6);
+        }
+    }
+    vmx_scene_destroy(mScene);
+    mScene = nullptr;
+    // NULL,0 -> the reference's eight hard-coded spheres (meshEngine.cpp:377-500); leaf size 4 (bvh.h:29)
+    if (vmx_scene_create(pos.data(), nrm.data(), uv.data(), (uint32_t)faces, nullptr, 0, 4, mDevice, &mScene) != VMX_OK) {
+        std::fprintf(stderr, "HipPathTracer: %s\n", vmx_last_error());
+        return false;
+    }
+    mUploadedFrom = mEng;
+    mUploadedFaces = faces;
+    return true;
+}
+
+void HipPathTracer::Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) {
+    if (!mEng || !upload(mEng)) return;  // Render has no error channel (integrators.h:15): log and leave mImage untouched
+    for (Camera *cam : cameraList) {     // pathtracer.cpp:210
+        vmx_camera c;
+        std::memset(&c, 0, sizeof(c));
+        c.position[0] = cam->mPosition.x, c.position[1] = cam->mPosition.y, c.position[2] = cam->mPosition.z;
+        // Camera stores radians with x,y negated (camera.cpp:43-47); the ABI takes cameraSettings' degrees
+        c.rotation_deg[0] = (float)(-cam->mRotation.x * 180 / 3.1415926535);
+        c.rotation_deg[1] = (float)(-cam->mRotation.y * 180 / 3.1415926535);
+        c.rotation_deg[2] = (float)(cam->mRotation.z * 180 / 3.1415926535);
+        c.back_distance = cam->mDistToFilm;
+        c.back_size[0] = cam->sensorSizeX, c.back_size[1] = cam->sensorSizeY;
+        c.image_res[0] = cam->uImageU, c.image_res[1] = cam->uImageV;
+        c.rays_per_pixel = cam->uSamplesPerPixel;
+        vmx_opts o;
+        std::memset(&o, 0, sizeof(o));
+        o.seed = mSeed;
+        o.early_stop = 1;                    // pathtracer.cpp:290-311
+        o.sampling = VMX_SAMPLING_PARITY;    // r2 = 10*U, pathtracer.cpp:156
+        std::vector<float> frame((size_t)cam->RenderTargetSize * 5);
+        vmx_stats st;
+        if (vmx_render(mScene, &c, &o, frame.data(), &st) != VMX_OK) {
+            std::fprintf(stderr, "HipPathTracer: %s\n", vmx_last_error());
+            continue;
+        }
+        cam->uRaysFired = st.rays_primary + st.rays_secondary;  // camera.h:101 (the reference never fills it)
+        pixelValue pv;                                           // camera.h:49-58
+        for (uint64_t p = 0; p < cam->RenderTargetSize; ++p) {   // works for every renderMode (camera.cpp:88-124)
+            const float *s = &frame[p * 5];
+            pv.pixel = p, pv.red = s[0], pv.green = s[1], pv.blue = s[2], pv.alpha = s[3], pv.depth = s[4];
+            cam->setPixelValue(pv);
+        }
+    }
+}
+
+}  // namespace Vermilion
