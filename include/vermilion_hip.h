@@ -115,8 +115,9 @@ typedef struct vmx_stats {
     uint64_t kernel_launches;
     double ms_total;            /* wall time of the call, host clock                   */
     double ms_device;           /* hipEvent time of the device work on the render stream */
-    vmx_stage_stats primary;
-    vmx_stage_stats bounce;
+    vmx_stage_stats primary; /* ms/launches: the depth-0 traversal kernel                  */
+    vmx_stage_stats bounce;  /* ms/launches: bounce traversal kernels + the tail kernel    */
+    vmx_stage_stats shade;   /* ms/launches only: the shading kernels of the split wavefront */
 } vmx_stats;
 
 typedef struct vmx_scene_desc {

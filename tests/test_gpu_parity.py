@@ -125,9 +125,13 @@ def test_frame_bit_exact(pair, early_stop, sampling):
     ref, rst = pair.cpu.render(cam, opts)
     assert img.shape == (H, W, 5)
     assert np.array_equal(bits(img), bits(ref)), f"{int((bits(img) != bits(ref)).any(axis=2).sum())} pixels differ"
-    assert st["rays_primary"] == rst["rays_primary"] and st["rays_secondary"] == rst["rays_secondary"]
+    if st["samples_discarded"] == 0:
+        assert st["rays_primary"] == rst["rays_primary"] and st["rays_secondary"] == rst["rays_secondary"]
+    else:  # speculative samples that an early stop discarded were traced too
+        assert st["rays_primary"] == rst["rays_primary"] + st["samples_discarded"]
     assert st["samples"] == rst["samples"] == int(img[:, :, 4].sum())
-    assert st["samples_discarded"] == 0
+    if not early_stop:
+        assert st["samples_discarded"] == 0  # speculation only happens under early stop
 
 
 @pytest.mark.parametrize("name", ["cornell8", "lattice"])
@@ -226,7 +230,9 @@ def test_custom_sphere_tables():
             img, st = p.gpu.render(cam, opts)
             ref, rst = p.cpu.render(cam, opts)
             assert np.array_equal(bits(img), bits(ref))
-            assert st["rays_secondary"] == rst["rays_secondary"]
+            if st["samples_discarded"] == 0:
+                assert st["rays_secondary"] == rst["rays_secondary"]
+            assert st["samples"] == rst["samples"]
         if n:
             assert img[:, :, :3].mean() > 0.01  # the area light actually lights the set
         p.close()

@@ -60,10 +60,11 @@ def check_scene(name, W, H, spp, nrays=200000):
     rtri, rt = osc.trace(po, pd)
     print("  primary_ids: id mismatches", int((tri != rtri).sum()), " t-bit mismatches", int((bits(t) != bits(rt)).sum()))
     # megakernel pipeline must give the same frame
-    opts = va.make_opts(seed=9, early_stop=True, pipeline=1)
-    img2, st2 = sc.render(cam, opts)
     img1, st1 = sc.render(cam, va.make_opts(seed=9, early_stop=True))
-    print("  pipeline=1 vs 0 frame equal:", np.array_equal(bits(img1), bits(img2)), f" {st2['ms_device']:.1f} ms vs {st1['ms_device']:.1f} ms")
+    for pl in (1, 2, 3):
+        img2, st2 = sc.render(cam, va.make_opts(seed=9, early_stop=True, pipeline=pl))
+        print(f"  pipeline={pl} vs 0 frame equal:", np.array_equal(bits(img1), bits(img2)), f" {st2['ms_device']:.1f} ms vs {st1['ms_device']:.1f} ms",
+              "rays equal:", st1["rays_secondary"] == st2["rays_secondary"])
     sc.close()
 
 if __name__ == "__main__":

@@ -23,7 +23,15 @@ def main():
         es = int(mode[2]); sampling = int(mode[4]); extra = mode[5:]
         kw = {}
         if "m" in extra: kw["pipeline"] = 1
+        if "o" in extra: kw["pipeline"] = 2
+        if "O" in extra: kw["pipeline"] = 3
         if "c" in extra: kw["collect_counters"] = True
+        if os.environ.get("REFILL"): kw["refill_min"] = int(os.environ["REFILL"])
+        if os.environ.get("SHADE"): kw["shade_min"] = int(os.environ["SHADE"])
+        if os.environ.get("TAIL"): kw["tail_threshold"] = int(os.environ["TAIL"])
+        if os.environ.get("MAXP"): kw["max_paths"] = int(os.environ["MAXP"])
+        if os.environ.get("LEAF"): kw["leaf_min"] = int(os.environ["LEAF"])
+        if os.environ.get("LDSE"): kw["lds_entries"] = int(os.environ["LDSE"])
         for r in range(reps):
             opts = va.make_opts(seed=1, early_stop=bool(es), sampling=sampling, **kw)
             t0 = time.time()
@@ -34,9 +42,10 @@ def main():
             dt = time.time() - t0
             rays = st["rays_primary"] + st["rays_secondary"]
             p, b = st["primary"], st["bounce"]
+            sh = st["shade"]
             print(f"{mode} rep{r}: {rays/1e6:.1f} Mrays  dev {st['ms_device']:.1f} ms  wall {dt*1e3:.1f} ms -> {rays/st['ms_device']/1e3:.1f} Mrays/s | "
                   f"primary {p['rays']/1e6:.1f}M rays {p['ms']:.1f} ms x{p['launches']} ({p['rays']/max(p['ms'],1e-9)/1e3:.0f} Mr/s) | bounce {b['rays']/1e6:.1f}M rays {b['ms']:.1f} ms x{b['launches']} | "
-                  f"passes {st['passes']} launches {st['kernel_launches']} samples {st['samples']/1e6:.1f}M disc {st['samples_discarded']}"
+                  f"shade {sh['ms']:.1f} ms x{sh['launches']} | passes {st['passes']} launches {st['kernel_launches']} samples {st['samples']/1e6:.1f}M disc {st['samples_discarded']}"
                   + (f" inner/ray {(p['inner_visits']+b['inner_visits'])/rays:.1f} tri/ray {(p['tri_tests']+b['tri_tests'])/rays:.1f}" if "c" in extra else ""))
     sc.close()
 

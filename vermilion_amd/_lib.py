@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvermilion_hip.so")
+LIB_PATH = os.environ.get("VMX_LIB") or os.path.join(_HERE, "libvermilion_hip.so")  # VMX_LIB: A/B builds
 
 VMX_OK = 0
 VMX_ERR_INVALID = 1
@@ -85,12 +85,14 @@ class Stats(C.Structure):
         ("ms_device", C.c_double),
         ("primary", StageStats),
         ("bounce", StageStats),
+        ("shade", StageStats),
     ]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("primary", "bounce")}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("primary", "bounce", "shade")}
         d["primary"] = self.primary.as_dict()
         d["bounce"] = self.bounce.as_dict()
+        d["shade"] = self.shade.as_dict()
         return d
 
 

@@ -104,6 +104,10 @@ struct EventPool {
 struct Workspace {
     DevBuf<unsigned char> queue_planes[2];
     DevBuf<unsigned int> queue_counts;  // 2 * kSubQueues * 32
+    DevBuf<unsigned int> heads;         // kSubQueues * 32 reservation heads of k_paths
+    DevBuf<unsigned char> overflow_stack;  // k_paths: stack levels beyond the LDS part
+    DevBuf<unsigned char> rayA, rayB, rngA, rngB, hit;  // split wavefront: per-path state
+    DevBuf<unsigned int> ids[2], id_counts;             // split wavefront: live path ids
     DevBuf<unsigned char> rad;          // float4 per path of a pass
     DevBuf<unsigned char> accum;        // float4 per local pixel
     DevBuf<unsigned int> count, cursor, active[2], next_count;
@@ -113,7 +117,9 @@ struct Workspace {
     uint32_t order_w = 0, order_rows = 0;
     EventPool events;
     void release() {
-        queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release();
+        queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), heads.release(), overflow_stack.release();
+        rayA.release(), rayB.release(), rngA.release(), rngB.release(), hit.release();
+        ids[0].release(), ids[1].release(), id_counts.release();
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
     }
@@ -249,14 +255,16 @@ struct TimedLaunch {
 };
 
 // reads the 16 sub-queue tails; returns total and the largest
-int read_counts(vmx_scene *sc, unsigned int *d_counts, hipStream_t s, uint64_t &total, uint32_t &largest) {
+int read_counts(vmx_scene *sc, unsigned int *d_counts, hipStream_t s, uint64_t &total, uint32_t &largest,
+                uint32_t sub_capacity = 0xffffffffu) {
     unsigned int h[kSubQueues * 32];
     HIP_TRY(hipMemcpyAsync(h, d_counts, sizeof(h), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     total = 0, largest = 0;
     for (uint32_t q = 0; q < kSubQueues; ++q) {
-        total += h[q * 32];
-        largest = std::max(largest, h[q * 32]);
+        const uint32_t c = std::min(h[q * 32], sub_capacity);  // an overflowing append leaves the tail high
+        total += c;
+        largest = std::max(largest, c);
     }
     (void)sc;
     return VMX_OK;
@@ -290,6 +298,117 @@ int run_queue(vmx_scene *sc, float r2scale, QueueDev q[2], int cur, void *rad, D
     return VMX_OK;
 }
 
+struct Tuning {
+    uint32_t refill_min, shade_min, leaf_min, lds_entries, tail_threshold;
+};
+
+Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
+    Tuning tn;
+    tn.refill_min = o->reserved[3] ? o->reserved[3] : 16u;
+    tn.shade_min = o->reserved[4] ? o->reserved[4] : 16u;
+    tn.leaf_min = o->reserved[5] ? o->reserved[5] : 16u;
+    const uint32_t cap = o->reserved[6] ? o->reserved[6] : 10u;  // 11 x 512 B per wave: 28 waves/CU fit in 160 KiB
+    tn.lds_entries = std::min(sc->dev.stack_entries, cap);
+    tn.tail_threshold = o->reserved[2] ? o->reserved[2] : (256u << 10);
+    return tn;
+}
+
+constexpr uint32_t kPathsBlock = 256;
+
+// fills the stack fields of a WorkDev and makes sure the global overflow slab is large enough
+int bind_stack(vmx_scene *sc, const Tuning &tn, uint32_t grid, WorkDev &wk) {
+    wk.lds_entries = tn.lds_entries;
+    wk.leaf_min = tn.leaf_min;
+    wk.overflow_entries = sc->dev.stack_entries > tn.lds_entries ? sc->dev.stack_entries - tn.lds_entries : 1u;
+    const size_t waves = (size_t)grid * (kPathsBlock / 64);
+    if (sc->ws.overflow_stack.ensure(waves * wk.overflow_entries * 64 * 8))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the overflow stack");
+    wk.overflow_stack = sc->ws.overflow_stack.p;
+    return VMX_OK;
+}
+
+LaunchCfg paths_cfg(const vmx_scene *sc, const Tuning &tn, uint64_t items, int blocks_per_cu) {
+    LaunchCfg c;
+    c.block = kPathsBlock;
+    c.lds_bytes = (kPathsBlock / 64) * (tn.lds_entries + 1) * 512;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    uint64_t grid = (uint64_t)sc->num_cus * (uint64_t)blocks_per_cu;
+    const uint64_t need = (items + kPathsBlock - 1) / kPathsBlock;
+    if (need < grid) grid = std::max<uint64_t>(1, need);
+    c.grid = (uint32_t)grid;
+    return c;
+}
+
+// ---- split wavefront (pipeline 0): k_trace_q + k_shade + id queues ---------------------------
+int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[2]) {
+    Workspace &ws = sc->ws;
+    const uint32_t sub_cap = (uint32_t)(nslots / kSubQueues + 1024);
+    if (ws.rayA.ensure(nslots * 16) || ws.rayB.ensure(nslots * 16) || ws.rngA.ensure(nslots * 16) ||
+        ws.rngB.ensure(nslots * 16) || ws.hit.ensure(nslots * 8) || ws.rad.ensure(nslots * 16) ||
+        ws.ids[0].ensure((size_t)sub_cap * kSubQueues) || ws.ids[1].ensure((size_t)sub_cap * kSubQueues) ||
+        ws.id_counts.ensure(2 * kSubQueues * 32) || ws.heads.ensure(kSubQueues * 32) || ws.counters.ensure(1))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the path arrays");
+    pa.rayA = ws.rayA.p, pa.rayB = ws.rayB.p, pa.rngA = ws.rngA.p, pa.rngB = ws.rngB.p;
+    pa.hit = ws.hit.p, pa.rad = ws.rad.p;
+    for (int i = 0; i < 2; ++i) {
+        q[i].ids = ws.ids[i].p;
+        q[i].counts = ws.id_counts.p + (size_t)i * kSubQueues * 32;
+        q[i].sub_capacity = sub_cap;
+        q[i].pad = 0;
+    }
+    return VMX_OK;
+}
+
+// bounce generations of the split wavefront: trace + shade per generation while many paths are
+// alive, then one launch that follows the remaining paths to their end
+int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int cur, DevCounters *ctr, bool count,
+            const Tuning &tn, hipStream_t s, std::vector<TimedLaunch> &timed, uint64_t &launches, int trace_blocks,
+            int tail_blocks) {
+    Workspace &ws = sc->ws;
+    PixelStateDev nopx{nullptr, nullptr, nullptr};
+    for (;;) {
+        uint64_t total;
+        uint32_t largest;
+        int rc = read_counts(sc, q[cur].counts, s, total, largest, q[cur].sub_capacity);
+        if (rc) return rc;
+        if (total == 0) break;
+        const bool tail = total <= tn.tail_threshold;
+        WorkDev wk;
+        std::memset(&wk, 0, sizeof(wk));
+        wk.heads = ws.heads.p;
+        wk.nsrc = kSubQueues;
+        wk.refill_min = tn.refill_min, wk.shade_min = tn.shade_min;
+        wk.qids = q[cur];
+        LaunchCfg cfg = paths_cfg(sc, tn, total, tail ? tail_blocks : trace_blocks);
+        rc = bind_stack(sc, tn, cfg.grid, wk);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
+        TimedLaunch tl{ws.events.get(), ws.events.get(), 1};
+        if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(tl.a, s));
+        if (tail) {
+            LAUNCH_TRY(launch_tail(sc->dev, fr, wk, pa, ctr, count, cfg, s));
+            HIP_TRY(hipEventRecord(tl.b, s));
+            timed.push_back(tl);
+            launches += 2;
+            break;
+        }
+        LAUNCH_TRY(launch_trace_q(sc->dev, fr, wk, nopx, pa, ctr, count, true, cfg, s));
+        HIP_TRY(hipEventRecord(tl.b, s));
+        timed.push_back(tl);
+        HIP_TRY(hipMemsetAsync(q[cur ^ 1].counts, 0, kSubQueues * 32 * 4, s));
+        TimedLaunch ts{ws.events.get(), ws.events.get(), 2};
+        if (!ts.a || !ts.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(ts.a, s));
+        LAUNCH_TRY(launch_shade(sc->dev, fr, wk, nopx, pa, q[cur ^ 1], (largest + 255) / 256, ctr, true, s));
+        HIP_TRY(hipEventRecord(ts.b, s));
+        timed.push_back(ts);
+        launches += 4;
+        cur ^= 1;
+    }
+    return VMX_OK;
+}
+
 int ensure_queues(vmx_scene *sc, uint32_t sub_capacity, QueueDev q[2]) {
     Workspace &ws = sc->ws;
     const size_t cap = (size_t)sub_capacity * kSubQueues;
@@ -299,6 +418,7 @@ int ensure_queues(vmx_scene *sc, uint32_t sub_capacity, QueueDev q[2]) {
     }
     int e = ws.queue_counts.ensure(2 * kSubQueues * 32);
     if (e) return fail(VMX_ERR_NOMEM, "queue counters");
+    if (ws.heads.ensure(kSubQueues * 32)) return fail(VMX_ERR_NOMEM, "work heads");
     for (int i = 0; i < 2; ++i) {
         q[i].planes = ws.queue_planes[i].p;
         q[i].counts = ws.queue_counts.p + (size_t)i * kSubQueues * 32;
@@ -313,9 +433,10 @@ int finish_stats(vmx_scene *sc, hipStream_t s, std::vector<TimedLaunch> &timed, 
                  std::chrono::steady_clock::time_point t0) {
     Workspace &ws = sc->ws;
     HIP_TRY(hipStreamSynchronize(s));
-    if (!stats) return VMX_OK;
     DevCounters h;
     HIP_TRY(hipMemcpy(&h, ws.counters.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.overflow) return fail(VMX_ERR_NOMEM, "path queue overflow (sub-queues full); lower max paths per pass");
+    if (!stats) return VMX_OK;
     std::memset(stats, 0, sizeof(*stats));
     stage_out(stats->primary, h.stage[0]);
     stage_out(stats->bounce, h.stage[1]);
@@ -328,7 +449,7 @@ int finish_stats(vmx_scene *sc, hipStream_t s, std::vector<TimedLaunch> &timed, 
     for (auto &tl : timed) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, tl.a, tl.b));
-        vmx_stage_stats &st = tl.stage == 0 ? stats->primary : stats->bounce;
+        vmx_stage_stats &st = tl.stage == 0 ? stats->primary : (tl.stage == 1 ? stats->bounce : stats->shade);
         st.ms += ms;
         st.launches++;
     }
@@ -350,30 +471,57 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     const uint32_t W = fr.width, rows = fr.local_rows;
     const uint32_t npix = W * rows;
     const bool count = opts->collect_counters != 0;
-    const bool mega = opts->reserved[0] == 1;
+    // pipeline forms (all produce the same frame, bit for bit):
+    //   0 split wavefront: k_trace_q + k_shade + id compaction (default)
+    //   1 k_paths: refilling lanes keep their path to its end (no queues)
+    //   2 first-generation k_primary/k_bounce wavefront   3 k_primary following every path to the end
+    const uint32_t pipeline = opts->reserved[0];
+    if (pipeline > 3) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    const bool split = pipeline == 0;
+    const bool refill = pipeline == 1;
+    const bool mega = pipeline == 1 || pipeline == 3;
+    const Tuning tn = make_tuning(sc, opts);
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
         return VMX_OK;
     }
 
     // pass sizing: at most max_paths paths in flight
-    const uint64_t max_paths = opts->reserved[1] ? opts->reserved[1] : (16ull << 20);
+    // paths in flight per pass: 128 M path slots = 11 GB of per-path state (288 GB of HBM per GPU);
+    // large passes keep the small late-bounce launches few
+    const uint64_t max_paths = opts->reserved[1] ? opts->reserved[1] : (128ull << 20);
     uint32_t smax = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
     if (opts->samples_per_batch) smax = opts->samples_per_batch;
     smax = std::min(smax, fr.kmax);
+    const uint32_t smax_alloc = smax;  // buffers are sized for this many samples per pixel and pass
 
     int pb = 1, bb = 1;
     const uint32_t lds = (sc->block / 64) * sc->dev.stack_entries * 512;
+    int rb = 1;
     HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, lds, count, &pb, &bb));
-    if (pb < 1 || bb < 1) return fail(VMX_ERR_HIP, "kernel does not fit on a CU (LDS stack too deep?)");
+    HIP_TRY((hipError_t)query_paths_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_entries + 1) * 512, count, &rb));
+    if (pb < 1 || bb < 1 || rb < 1) return fail(VMX_ERR_HIP, "kernel does not fit on a CU (LDS stack too deep?)");
 
     // buffers
     const uint32_t n_pad_max = (npix + 63u) & ~63u;
     const uint32_t tiles8_max = (((n_pad_max + sc->block - 1) / sc->block) + 7u) & ~7u;
-    const uint32_t sub_cap = ((tiles8_max * smax) / kSubQueues + 2) * sc->block;
+    // static item->sub-queue map (pipeline 2): exact bound; dynamic refill (pipeline 0): 25 % slack
+    // per sub-queue, overflow falls through to the next sub-queue and is reported if nothing fits
+    uint32_t sub_cap = ((tiles8_max * smax) / kSubQueues + 2) * sc->block;
+    sub_cap = sub_cap + sub_cap / 4 + 4096;
     QueueDev q[2];
-    rc = ensure_queues(sc, sub_cap, q);
-    if (rc) return rc;
+    PathArrays pa{};
+    IdQueue qi[2];
+    int tb = 1;
+    if (split) {
+        rc = ensure_paths(sc, (size_t)n_pad_max * smax, pa, qi);
+        if (rc) return rc;
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_entries + 1) * 512, count, &tb));
+        if (tb < 1) return fail(VMX_ERR_HIP, "trace kernel does not fit on a CU");
+    } else {
+        rc = ensure_queues(sc, sub_cap, q);
+        if (rc) return rc;
+    }
     if (ws.rad.ensure((size_t)n_pad_max * smax * 16) || ws.accum.ensure((size_t)npix * 16) ||
         ws.count.ensure(npix) || ws.cursor.ensure(npix) || ws.active[0].ensure(npix) ||
         ws.active[1].ensure(npix) || ws.next_count.ensure(32) || ws.counters.ensure(1))
@@ -400,7 +548,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     int cur_list = 0;
     uint32_t n_uniform = 0;  // samples every active pixel has taken while no early stop was possible
     uint32_t k_fixed = 0;    // fixed-spp mode: samples issued so far
-    const uint32_t tail_threshold = opts->reserved[2] ? opts->reserved[2] : (256u << 10);
+    uint64_t last_pass_pixels = 0, last_pass_breaks = 0;  // early-stop statistics of the previous pass
+    const uint32_t tail_threshold = tn.tail_threshold;
     while (n_active > 0) {
         uint32_t S;
         if (fr.early_stop) {
@@ -410,7 +559,18 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
                 S = std::min({fr.nmin + 1 - n_uniform, smax, fr.kmax - n_uniform});
                 n_uniform += S;
             } else {
+                // Past that point a pixel may stop after any sample.  While most pixels are still
+                // active one sample per pass is issued (nothing speculative); once the active set is
+                // small, up to 16 samples per pixel are issued at once and k_resolve discards what
+                // follows an early stop (same frame, fewer launch-bound passes).
+                // Speculation only pays for pixels that keep sampling: it is used when fewer than
+                // 1 in 8 of the active pixels stopped a stratum in the previous pass.
+                const uint64_t spec = 1ull << 20;
                 S = 1;
+                if (last_pass_pixels > 0 && last_pass_breaks * 8 < last_pass_pixels)
+                    S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, spec / (2ull * n_active)), 16);
+                S = (uint32_t)std::min<uint64_t>(S, ((uint64_t)n_pad_max * smax_alloc) / ((n_active + 63u) & ~63u));
+                S = std::max(S, 1u);
             }
         } else {
             if (k_fixed >= fr.kmax) break;
@@ -419,30 +579,80 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         }
         const uint32_t n_pad = (n_active + 63u) & ~63u;
         const uint32_t tiles8 = (((n_pad + sc->block - 1) / sc->block) + 7u) & ~7u;
-        LaunchCfg cfg = trace_cfg(sc, tiles8 * S, pb);
-        if (!mega) LAUNCH_TRY(launch_zero_u32(q[0].counts, kSubQueues * 32, s));
+        if (!mega && !split) HIP_TRY(hipMemsetAsync(q[0].counts, 0, kSubQueues * 32 * 4, s));
         TimedLaunch tl{ws.events.get(), ws.events.get(), 0};
         if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
-        HIP_TRY(hipEventRecord(tl.a, s));
-        LAUNCH_TRY(launch_primary(sc->dev, fr, ws.active[cur_list].p, n_active, S, px, q[0], ws.rad.p,
-                                  ws.counters.p, count, mega, cfg, s));
-        HIP_TRY(hipEventRecord(tl.b, s));
+        if (split) {
+            WorkDev wk;
+            std::memset(&wk, 0, sizeof(wk));
+            wk.heads = ws.heads.p;
+            wk.nsrc = 8;
+            wk.refill_min = tn.refill_min, wk.shade_min = tn.shade_min;
+            wk.active = ws.active[cur_list].p;
+            wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S;
+            wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;
+            wk.band_items = wk.band_slots * S;
+            LaunchCfg cfg = paths_cfg(sc, tn, (uint64_t)n_pad * S, tb);
+            rc = bind_stack(sc, tn, cfg.grid, wk);
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
+            LAUNCH_TRY(launch_raygen(fr, wk, px, pa, s));
+            HIP_TRY(hipEventRecord(tl.a, s));
+            LAUNCH_TRY(launch_trace_q(sc->dev, fr, wk, px, pa, ws.counters.p, count, false, cfg, s));
+            HIP_TRY(hipEventRecord(tl.b, s));
+            HIP_TRY(hipMemsetAsync(qi[0].counts, 0, kSubQueues * 32 * 4, s));
+            TimedLaunch ts{ws.events.get(), ws.events.get(), 2};
+            if (!ts.a || !ts.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(ts.a, s));
+            LAUNCH_TRY(launch_shade(sc->dev, fr, wk, px, pa, qi[0], 0, ws.counters.p, false, s));
+            HIP_TRY(hipEventRecord(ts.b, s));
+            timed.push_back(ts);
+            launches += 2;
+        } else if (refill) {
+            WorkDev wk;
+            std::memset(&wk, 0, sizeof(wk));
+            wk.heads = ws.heads.p;
+            wk.nsrc = 8;
+            wk.refill_min = tn.refill_min, wk.shade_min = tn.shade_min;
+            wk.active = ws.active[cur_list].p;
+            wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S;
+            wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;
+            wk.band_items = wk.band_slots * S;
+            LaunchCfg cfg = paths_cfg(sc, tn, (uint64_t)n_pad * S, rb);
+            rc = bind_stack(sc, tn, cfg.grid, wk);
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
+            HIP_TRY(hipEventRecord(tl.a, s));
+            LAUNCH_TRY(launch_paths(sc->dev, fr, wk, px, q[0], ws.rad.p, ws.counters.p, count, false, mega, cfg, s));
+            HIP_TRY(hipEventRecord(tl.b, s));
+        } else {
+            LaunchCfg cfg = trace_cfg(sc, tiles8 * S, pb);
+            HIP_TRY(hipEventRecord(tl.a, s));
+            LAUNCH_TRY(launch_primary(sc->dev, fr, ws.active[cur_list].p, n_active, S, px, q[0], ws.rad.p,
+                                      ws.counters.p, count, mega, cfg, s));
+            HIP_TRY(hipEventRecord(tl.b, s));
+        }
         timed.push_back(tl);
         launches += 2;
-        if (!mega) {
-            rc = run_queue(sc, fr.r2scale, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed,
-                           launches, bb);
+        if (split) {
+            rc = run_ids(sc, fr, pa, qi, 0, ws.counters.p, count, tn, s, timed, launches, tb, rb);
+            if (rc) return rc;
+        } else if (!mega) {
+            rc = run_queue(sc, fr.r2scale, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed, launches,
+                           bb);
             if (rc) return rc;
         }
-        HIP_TRY(hipMemsetAsync(ws.next_count.p, 0, 4, s));
+        HIP_TRY(hipMemsetAsync(ws.next_count.p, 0, 8, s));
         LAUNCH_TRY(launch_resolve(fr, ws.active[cur_list].p, n_active, S, ws.rad.p, px, ws.active[cur_list ^ 1].p,
                                   ws.next_count.p, d_out, ws.counters.p, s));
         launches++;
         passes++;
-        unsigned int h_next = 0;
-        HIP_TRY(hipMemcpyAsync(&h_next, ws.next_count.p, 4, hipMemcpyDeviceToHost, s));
+        unsigned int h_next[2] = {0, 0};  // [0] pixels still active, [1] pixels that stopped a stratum early
+        HIP_TRY(hipMemcpyAsync(h_next, ws.next_count.p, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        n_active = h_next;
+        last_pass_pixels = n_active;
+        last_pass_breaks = h_next[1];
+        n_active = h_next[0];
         cur_list ^= 1;
     }
     HIP_TRY(hipEventRecord(ev1, s));
@@ -674,6 +884,7 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     vmx_scene *sc = const_cast<vmx_scene *>(csc);
     if (!sc || !origin || !dir || !opts || !out) return fail(VMX_ERR_INVALID, "NULL argument");
     if (opts->sampling > VMX_SAMPLING_CORRECTED) return fail(VMX_ERR_INVALID, "unknown sampling mode");
+    if (opts->reserved[0] > 3) return fail(VMX_ERR_INVALID, "unknown pipeline form");
     if (n == 0) return VMX_OK;
     const auto t0 = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> lock(sc->mu);
@@ -682,20 +893,32 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     Workspace &ws = sc->ws;
     hipStream_t s = sc->stream;
     const bool count = opts->collect_counters != 0;
-    const float r2scale = opts->sampling == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
-    // k_radiance_init: grid <= 4096 blocks of 256, sub-queue = block iteration % 16
-    const uint32_t blocks = (n + 255) / 256;
-    const uint32_t sub_cap = (blocks / kSubQueues + 2) * 256;
+    const bool legacy = opts->reserved[0] >= 2;  // first-generation kernels (96-byte path records)
+    const Tuning tn = make_tuning(sc, opts);
+    FrameDev fr;
+    std::memset(&fr, 0, sizeof(fr));
+    fr.r2scale = opts->sampling == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
     QueueDev q[2];
-    rc = ensure_queues(sc, sub_cap, q);
-    if (rc) return rc;
+    PathArrays pa{};
+    IdQueue qi[2];
+    int bb = 1, pb = 1, tb = 1, rb = 1;
+    const uint32_t lds_full = (sc->block / 64) * sc->dev.stack_entries * 512;
+    const uint32_t lds_paths = (kPathsBlock / 64) * (tn.lds_entries + 1) * 512;
+    if (legacy) {
+        const uint32_t blocks = (n + 255) / 256;
+        const uint32_t sub_cap0 = (blocks / kSubQueues + 2) * 256;
+        rc = ensure_queues(sc, sub_cap0 + sub_cap0 / 4 + 4096, q);
+        if (rc) return rc;
+        if (ws.rad.ensure((size_t)n * 16) || ws.counters.ensure(1)) return fail(VMX_ERR_NOMEM, "hipMalloc failed");
+        HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, lds_full, count, &pb, &bb));
+    } else {
+        rc = ensure_paths(sc, n, pa, qi);
+        if (rc) return rc;
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, lds_paths, count, &tb));
+        HIP_TRY((hipError_t)query_paths_blocks_per_cu(kPathsBlock, lds_paths, count, &rb));
+    }
     DevBuf<float> d_o, d_d;
-    if (d_o.ensure((size_t)n * 3) || d_d.ensure((size_t)n * 3) || ws.rad.ensure((size_t)n * 16) ||
-        ws.counters.ensure(1))
-        return fail(VMX_ERR_NOMEM, "hipMalloc failed");
-    int pb = 1, bb = 1;
-    const uint32_t lds = (sc->block / 64) * sc->dev.stack_entries * 512;
-    HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, lds, count, &pb, &bb));
+    if (d_o.ensure((size_t)n * 3) || d_d.ensure((size_t)n * 3)) return fail(VMX_ERR_NOMEM, "hipMalloc failed");
     ws.events.reset();
     std::vector<TimedLaunch> timed;
     uint64_t launches = 0;
@@ -705,11 +928,18 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
         HIP_TRY(hipMemcpyAsync(d_d.p, dir, (size_t)n * 12, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(ev0, s));
         HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
-        LAUNCH_TRY(launch_zero_u32(q[0].counts, kSubQueues * 32, s));
-        LAUNCH_TRY(launch_radiance_init(d_o.p, d_d.p, n, opts->seed, q[0], s));
-        launches += 2;
-        const uint32_t tail_threshold = opts->reserved[2] ? opts->reserved[2] : (256u << 10);
-        int r = run_queue(sc, r2scale, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed, launches, bb);
+        int r;
+        if (legacy) {
+            HIP_TRY(hipMemsetAsync(q[0].counts, 0, kSubQueues * 32 * 4, s));
+            LAUNCH_TRY(launch_radiance_init(d_o.p, d_d.p, n, opts->seed, q[0], s));
+            launches += 2;
+            r = run_queue(sc, fr.r2scale, q, 0, ws.rad.p, ws.counters.p, count, tn.tail_threshold, s, timed, launches, bb);
+        } else {
+            HIP_TRY(hipMemsetAsync(qi[0].counts, 0, kSubQueues * 32 * 4, s));
+            LAUNCH_TRY(launch_radiance_init_ids(d_o.p, d_d.p, n, opts->seed, pa, qi[0], s));
+            launches += 2;
+            r = run_ids(sc, fr, pa, qi, 0, ws.counters.p, count, tn, s, timed, launches, tb, rb);
+        }
         if (r) return r;
         HIP_TRY(hipEventRecord(ev1, s));
         HIP_TRY(hipMemcpyAsync(out, ws.rad.p, (size_t)n * 16, hipMemcpyDeviceToHost, s));

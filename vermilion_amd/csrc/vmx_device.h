@@ -78,7 +78,7 @@ struct StageCounters {
 };
 struct DevCounters {
     StageCounters stage[2];
-    unsigned long long samples, discarded, pixels_done;
+    unsigned long long samples, discarded, pixels_done, overflow;
 };
 
 // Camera/frame constants for ray generation (pathtracer.cpp:216-221, 251-280)

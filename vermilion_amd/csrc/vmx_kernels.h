@@ -21,6 +21,45 @@ struct PixelStateDev {
     unsigned int *cursor;     // next linear sample index k
 };
 
+// Per-pass path state, one slot per path id `pid` = sample_plane * n_pad + slot (fixed for the
+// pass: compaction between bounces moves 4-byte ids, never the state).
+struct PathArrays {
+    void *rayA;   // float4 (o.x, o.y, o.z, d.x)            bounce rays only
+    void *rayB;   // float4 (d.y, d.z, bits(depth), 0)
+    void *rngA;   // float4 = xoshiro s0, s1
+    void *rngB;   // float4 = xoshiro s2, s3
+    void *hit;    // float2 (t of the BVH query, bits(leaf slot or -1))
+    void *rad;    // float4 accumColour, updated in place; final when the path ends
+};
+
+// compacted list of live path ids: kSubQueues sub-lists, each `sub_capacity` ids long
+struct IdQueue {
+    unsigned int *ids;
+    unsigned int *counts;   // counter q at counts[q*32]
+    uint32_t sub_capacity;
+    uint32_t pad;
+};
+
+// work source of k_paths
+struct WorkDev {
+    unsigned int *heads;        // [nsrc * 32] reservation heads, zeroed before the launch
+    uint32_t nsrc;              // 8 image bands (primary) or kSubQueues (queue)
+    uint32_t refill_min;        // refill when this many lanes of a wave are idle
+    uint32_t shade_min;         // shade when this many lanes have finished traversal
+    uint32_t leaf_min;          // run the triangle step when this many lanes sit at a leaf
+    uint32_t lds_entries;       // stack levels kept in LDS
+    uint32_t overflow_entries;  // deeper levels, in the global slab below (64 lanes x 8 B each)
+    void *overflow_stack;       // uint2[waves][overflow_entries][64]
+    // primary source
+    const unsigned int *active;
+    uint32_t n_active, n_pad, samples;
+    uint32_t band_slots;        // slots per band (multiple of 64)
+    uint32_t band_items;        // band_slots * samples
+    // queue source
+    QueueDev qin;     // first-generation kernels (96-byte path records)
+    IdQueue qids;     // k_trace_q / k_shade / tail (path ids)
+};
+
 struct LaunchCfg {
     uint32_t grid;            // persistent blocks
     uint32_t block;           // threads per block (multiple of 64)
@@ -51,6 +90,24 @@ int launch_bounce(const SceneDev &sc, float r2scale, QueueDev qin, uint32_t max_
                   void *rad, DevCounters *counters, bool count, bool loop_to_end, bool first_step,
                   LaunchCfg cfg, void *stream);
 // per-pixel accumulation in sample order, early-stop rule, pixel write, next active list
+// persistent kernel with per-lane refill: primary (ray generation) or queue source
+int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, QueueDev qout,
+                 void *rad, DevCounters *counters, bool count, bool from_queue, bool loop_to_end, LaunchCfg cfg,
+                 void *stream);
+int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks);
+// split wavefront: lean persistent trace kernel (vote-scheduled traversal, per-lane refill) ...
+int launch_raygen(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
+int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
+                   DevCounters *counters, bool count, bool from_queue, LaunchCfg cfg, void *stream);
+int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks);
+// ... and the wide shading kernel: RayCast tail + Radiance step + id compaction
+int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
+                 IdQueue qout, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream);
+// follows every queued path (ids) to its end in one launch
+int launch_tail(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathArrays pa, DevCounters *counters,
+                bool count, LaunchCfg cfg, void *stream);
+int launch_radiance_init_ids(const float *o, const float *d, uint32_t n, uint64_t seed, PathArrays pa,
+                             IdQueue qout, void *stream);
 int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,
                    const void *rad, PixelStateDev px, unsigned int *next_active,
                    unsigned int *next_count, float *out_rgbaz, DevCounters *counters, void *stream);

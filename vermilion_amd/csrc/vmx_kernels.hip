@@ -24,9 +24,14 @@
 // tails.  No MFMA: there is no dense contraction in this workload.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "vmx_kernels.h"
+
+#ifndef VMX_TRACE_WAVES_PER_SIMD
+#define VMX_TRACE_WAVES_PER_SIMD 7  // register budget of the trace kernel: 512 / 7 -> 72 VGPRs
+#endif
 
 namespace vmx {
 namespace {
@@ -128,13 +133,35 @@ __device__ __forceinline__ bool finite3(float x, float y, float z) {
 // Fast form: v_min/v_max.  Equal to the reference's compare-select form
 // whenever no slab product is NaN, which `exact == false` guarantees (finite
 // origin, finite non-zero reciprocal direction).
+// The min/max are issued as plain v_min/v_max/v_max3/v_min3 (inline asm): without it hipcc adds a
+// canonicalising v_max(x,x) in front of every fminf/fmaxf operand that comes out of a packed multiply.
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ bool box_fast(float lx, float ly, float lz, float hx, float hy, float hz,
                                          float ox, float oy, float oz, float ix, float iy, float iz,
                                          float &tnear) {
     const float t0x = (lx - ox) * ix, t0y = (ly - oy) * iy, t0z = (lz - oz) * iz;
     const float t1x = (hx - ox) * ix, t1y = (hy - oy) * iy, t1z = (hz - oz) * iz;
-    const float n = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-    const float f = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    const float n = vmax3(vmin(t0x, t1x), vmin(t0y, t1y), vmin(t0z, t1z));
+    const float f = vmin3(vmax(t0x, t1x), vmax(t0y, t1y), vmax(t0z, t1z));
     tnear = n;
     return n <= f;
 }
@@ -308,13 +335,9 @@ struct CastResult {
     bool material;
 };
 
-// MeshEngine::RayCast (meshEngine.cpp:239-509)
-template <bool COUNT>
-__device__ __forceinline__ void ray_cast(const SceneDev &sc, float ox, float oy, float oz, float dx,
-                                         float dy, float dz, uint2 *stk, CastResult &r, Cnt &cnt) {
-    float best;
-    int slot;
-    bvh_nearest<COUNT>(sc, ox, oy, oz, dx, dy, dz, stk, best, slot, cnt);
+// MeshEngine::RayCast after the BVH query (meshEngine.cpp:365-508): triangle normal, sphere table
+__device__ __forceinline__ void cast_finish(const SceneDev &sc, float ox, float oy, float oz, float dx,
+                                            float dy, float dz, float best, int slot, CastResult &r) {
     r.nearest = kInf;
     r.nx = r.ny = r.nz = 0.f;
     r.cr = r.cg = r.cb = 0.f;
@@ -348,12 +371,21 @@ __device__ __forceinline__ void ray_cast(const SceneDev &sc, float ox, float oy,
     }
 }
 
+// MeshEngine::RayCast (meshEngine.cpp:239-509)
+template <bool COUNT>
+__device__ __forceinline__ void ray_cast(const SceneDev &sc, float ox, float oy, float oz, float dx,
+                                         float dy, float dz, uint2 *stk, CastResult &r, Cnt &cnt) {
+    float best;
+    int slot;
+    bvh_nearest<COUNT>(sc, ox, oy, oz, dx, dy, dz, stk, best, slot, cnt);
+    cast_finish(sc, ox, oy, oz, dx, dy, dz, best, slot, r);
+}
+
 // ---------------------------------------------------------------------------
 // one iteration of Radiance's bounce loop (pathtracer.cpp:34-197)
 // ---------------------------------------------------------------------------
 struct Path {
     float ox, oy, oz, dx, dy, dz;
-    float tr, tg, tb;      // accumRadiance (rgb)
     float ar, ag, ab, aw;  // accumColour
     uint32_t depth, dest;
     Rng rng;
@@ -363,18 +395,17 @@ struct StepFlags {
     bool was_ray, tri_hit, continues;
 };
 
+// Radiance's loop body after RayCast (pathtracer.cpp:36-196).
 // returns true if the path continues with a new ray in P, false if accumColour is final
-template <bool COUNT>
-__device__ __forceinline__ bool path_step(const SceneDev &sc, float r2scale, Path &P, uint2 *stk,
-                                          StepFlags &fl, Cnt &cnt) {
-    CastResult c;
-    ray_cast<COUNT>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, stk, c, cnt);
+__device__ __forceinline__ bool path_shade(float r2scale, Path &P, const CastResult &c, StepFlags &fl) {
     fl.tri_hit = c.slot >= 0;
     fl.continues = false;
     if (!(c.nearest < kInf)) return false;  // pathtracer.cpp:36-41
-    P.ar = P.ar + P.tr * c.cr;              // :43 (w term adds 0)
-    P.ag = P.ag + P.tg * c.cg;
-    P.ab = P.ab + P.tb * c.cb;
+    // :43 — accumRadiance stays (1,1,1,1): the only factor ever applied to it is the white
+    // albedo of the untextured path (:75-79,153), so the product is exactly hitColour
+    P.ar = P.ar + c.cr;
+    P.ag = P.ag + c.cg;
+    P.ab = P.ab + c.cb;
     if (P.depth == 0) P.aw = c.nearest;                                   // :44-47
     if (sqrtf(dot3(c.cr, c.cg, c.cb, c.cr, c.cg, c.cb)) > 1.f) return false;  // :52
     P.depth++;
@@ -444,6 +475,14 @@ __device__ __forceinline__ bool path_step(const SceneDev &sc, float r2scale, Pat
     return true;
 }
 
+template <bool COUNT>
+__device__ __forceinline__ bool path_step(const SceneDev &sc, float r2scale, Path &P, uint2 *stk,
+                                          StepFlags &fl, Cnt &cnt) {
+    CastResult c;
+    ray_cast<COUNT>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, stk, c, cnt);
+    return path_shade(r2scale, P, c, fl);
+}
+
 // ---------------------------------------------------------------------------
 // path queue (SoA of float4 planes, 16 sub-queues)
 // ---------------------------------------------------------------------------
@@ -451,8 +490,8 @@ __device__ __forceinline__ void path_store(const QueueDev &q, uint32_t idx, cons
     float4 *pl = (float4 *)q.planes;
     const size_t cap = q.capacity;
     pl[idx] = make_float4(P.ox, P.oy, P.oz, P.dx);
-    pl[cap + idx] = make_float4(P.dy, P.dz, P.tr, P.tg);
-    pl[2 * cap + idx] = make_float4(P.tb, P.ar, P.ag, P.ab);
+    pl[cap + idx] = make_float4(P.dy, P.dz, 1.f, 1.f);
+    pl[2 * cap + idx] = make_float4(1.f, P.ar, P.ag, P.ab);
     pl[3 * cap + idx] = make_float4(P.aw, __uint_as_float(P.depth), __uint_as_float(P.dest), 0.f);
     pl[4 * cap + idx] = make_float4(__uint_as_float((uint32_t)P.rng.s0), __uint_as_float((uint32_t)(P.rng.s0 >> 32)),
                                     __uint_as_float((uint32_t)P.rng.s1), __uint_as_float((uint32_t)(P.rng.s1 >> 32)));
@@ -466,8 +505,8 @@ __device__ __forceinline__ void path_load(const QueueDev &q, uint32_t idx, Path 
     const float4 a = pl[idx], b = pl[cap + idx], c = pl[2 * cap + idx], d = pl[3 * cap + idx],
                  e = pl[4 * cap + idx], f = pl[5 * cap + idx];
     P.ox = a.x, P.oy = a.y, P.oz = a.z, P.dx = a.w;
-    P.dy = b.x, P.dz = b.y, P.tr = b.z, P.tg = b.w;
-    P.tb = c.x, P.ar = c.y, P.ag = c.z, P.ab = c.w;
+    P.dy = b.x, P.dz = b.y;
+    P.ar = c.y, P.ag = c.z, P.ab = c.w;
     P.aw = d.x, P.depth = __float_as_uint(d.y), P.dest = __float_as_uint(d.z);
     P.rng.s0 = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
     P.rng.s1 = (uint64_t)__float_as_uint(e.z) | ((uint64_t)__float_as_uint(e.w) << 32);
@@ -486,6 +525,35 @@ __device__ __forceinline__ void queue_append(const QueueDev &q, uint32_t sub, bo
     base = __shfl(base, __ffsll((long long)m) - 1, 64);
     const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (alive) path_store(q, sub * q.sub_capacity + base + rank, P);
+}
+
+// same, with an overflow check: a full sub-queue makes the wave try the next one
+// (its tail stays over-incremented; consumers clamp counts to sub_capacity).
+// Returns false if no sub-queue could take the wave's paths (host reports an error).
+__device__ __forceinline__ bool queue_append_checked(const QueueDev &q, uint32_t sub, bool alive, const Path &P) {
+    const unsigned long long m = __ballot(alive);
+    if (m == 0) return true;
+    const uint32_t n = (uint32_t)__popcll(m);
+    const uint32_t lane = lane_index();
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (uint32_t attempt = 0; attempt < kSubQueues; ++attempt) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&q.counts[sub * 32], n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + n <= q.sub_capacity) {
+            if (alive) path_store(q, sub * q.sub_capacity + base + rank, P);
+            return true;
+        }
+        if (base < q.sub_capacity) {
+            // partial room: the slots [base, cap) stay unwritten; mark them dead (depth = ~0)
+            float4 *pl = (float4 *)q.planes;
+            const uint32_t room = q.sub_capacity - base;
+            if (lane < room) pl[3 * (size_t)q.capacity + sub * q.sub_capacity + base + lane] =
+                make_float4(0.f, __uint_as_float(0xFFFFFFFFu), 0.f, 0.f);
+        }
+        sub = (sub + 1 == kSubQueues) ? 0 : sub + 1;
+    }
+    return false;
 }
 
 __device__ __forceinline__ void tally_add(Tally &tl, const StepFlags &fl, bool ran, uint32_t stage_depth0) {
@@ -558,6 +626,61 @@ __device__ __forceinline__ uint32_t global_pixel(const FrameDev &fr, uint32_t lp
     const uint32_t ls = lrow / fr.stripe_rows, r = lrow - ls * fr.stripe_rows;
     const uint32_t grow = (ls * fr.world + fr.rank) * fr.stripe_rows + r;
     return grow * fr.width + x;
+}
+
+// ---- path state in per-pass arrays (split wavefront) ---------------------------------------
+__device__ __forceinline__ void rng_store(const PathArrays &pa, uint32_t pid, const Rng &r) {
+    ((float4 *)pa.rngA)[pid] = make_float4(__uint_as_float((uint32_t)r.s0), __uint_as_float((uint32_t)(r.s0 >> 32)),
+                                           __uint_as_float((uint32_t)r.s1), __uint_as_float((uint32_t)(r.s1 >> 32)));
+    ((float4 *)pa.rngB)[pid] = make_float4(__uint_as_float((uint32_t)r.s2), __uint_as_float((uint32_t)(r.s2 >> 32)),
+                                           __uint_as_float((uint32_t)r.s3), __uint_as_float((uint32_t)(r.s3 >> 32)));
+}
+__device__ __forceinline__ void rng_load(const PathArrays &pa, uint32_t pid, Rng &r) {
+    const float4 e = ((const float4 *)pa.rngA)[pid], f = ((const float4 *)pa.rngB)[pid];
+    r.s0 = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
+    r.s1 = (uint64_t)__float_as_uint(e.z) | ((uint64_t)__float_as_uint(e.w) << 32);
+    r.s2 = (uint64_t)__float_as_uint(f.x) | ((uint64_t)__float_as_uint(f.y) << 32);
+    r.s3 = (uint64_t)__float_as_uint(f.z) | ((uint64_t)__float_as_uint(f.w) << 32);
+}
+__device__ __forceinline__ void ray_store(const PathArrays &pa, uint32_t pid, const Path &P) {
+    ((float4 *)pa.rayA)[pid] = make_float4(P.ox, P.oy, P.oz, P.dx);
+    ((float4 *)pa.rayB)[pid] = make_float4(P.dy, P.dz, __uint_as_float(P.depth), 0.f);
+}
+__device__ __forceinline__ void ray_load(const PathArrays &pa, uint32_t pid, Path &P) {
+    const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
+    P.ox = a.x, P.oy = a.y, P.oz = a.z, P.dx = a.w;
+    P.dy = b.x, P.dz = b.y, P.depth = __float_as_uint(b.z);
+}
+__device__ __forceinline__ void path_load_arrays(const PathArrays &pa, uint32_t pid, Path &P) {
+    ray_load(pa, pid, P);
+    rng_load(pa, pid, P.rng);
+    const float4 acc = ((const float4 *)pa.rad)[pid];
+    P.ar = acc.x, P.ag = acc.y, P.ab = acc.z, P.aw = acc.w;
+    P.dest = pid;
+}
+// id compaction: wave ballot + prefix popcount, one atomic per wave
+__device__ __forceinline__ void id_append(const IdQueue &q, uint32_t sub, bool alive, uint32_t pid) {
+    const unsigned long long m = __ballot(alive);
+    if (m == 0) return;
+    const uint32_t lane = lane_index();
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&q.counts[sub * 32], (uint32_t)__popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (alive) q.ids[(size_t)sub * q.sub_capacity + base + rank] = pid;
+}
+
+// band-local work item of the primary source -> path id, global pixel, sample index
+__device__ __forceinline__ bool primary_item(const FrameDev &fr, const WorkDev &wk, const PixelStateDev &px,
+                                             uint32_t j, uint32_t s_idx, uint32_t &pid, uint32_t &pixel,
+                                             uint32_t &k) {
+    if (s_idx >= wk.n_active) return false;
+    const uint32_t lp = wk.active[s_idx];
+    k = px.cursor[lp] + j;
+    if (k >= fr.kmax) return false;
+    pixel = global_pixel(fr, lp);
+    pid = j * wk.n_pad + s_idx;
+    return true;
 }
 
 // block-sized work item -> (sample plane j, first slot), XCD-aware:
@@ -681,7 +804,6 @@ __global__ void k_primary(SceneDev sc, FrameDev fr, const unsigned int *__restri
                 const uint32_t p = global_pixel(fr, lp);
                 primary_ray(fr, p, k, P.rng, P.dx, P.dy, P.dz);
                 P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz;
-                P.tr = P.tg = P.tb = 1.f;
                 P.ar = P.ag = P.ab = 0.f;
                 P.aw = -100.f;  // pathtracer.cpp:29
                 P.depth = 0;
@@ -728,7 +850,6 @@ __global__ void k_radiance_init(const float *__restrict__ o, const float *__rest
             (void)rng_next(P.rng);
             P.ox = o[i * 3], P.oy = o[i * 3 + 1], P.oz = o[i * 3 + 2];
             P.dx = d[i * 3], P.dy = d[i * 3 + 1], P.dz = d[i * 3 + 2];
-            P.tr = P.tg = P.tb = 1.f;
             P.ar = P.ag = P.ab = 0.f;
             P.aw = -100.f;
             P.depth = 0;
@@ -785,17 +906,605 @@ __global__ void k_bounce(SceneDev sc, float r2scale, QueueDev qin, uint32_t max_
     tally_flush<COUNT>(ctr, tl, c0, c1);
 }
 
+
+// ---------------------------------------------------------------------------
+// k_paths — persistent waves with per-lane refill.
+//
+// Every lane runs the state machine  fetch -> traverse (one BVH node per loop
+// iteration) -> shade -> {write radiance | continue (LOOP) | append to the
+// next queue}.  A lane that finishes does not idle until its wave is done: as
+// soon as `refill_min` lanes are idle the wave takes that many new items from
+// its work source (a wave-private reservation of 256 items, one atomic per
+// reservation), and as soon as `shade_min` lanes have finished traversal they
+// are shaded together.  Results do not depend on this scheduling: each path
+// carries its own RNG stream and radiance slot.
+//   SRC 0: work = (sample j, slot) pairs of the active-pixel list, in 8 bands
+//          of neighbouring tiles (band = block % 8 = XCD label; exhausted
+//          bands are stolen from), paths start with ray generation
+//   SRC 1: work = the 16 sub-queues of a path queue
+// ---------------------------------------------------------------------------
+// LDS holds levels [0, lds_entries) plus one scratch entry at index lds_entries; deeper levels
+// (rare) go to the per-wave global slab.  The LDS access is unconditional on a clamped index so
+// that it stays a ds_*_b64 (a select between the two address spaces turns into flat accesses).
+__device__ __forceinline__ void stack_push(uint2 *stk, uint2 *ovf, int lds_entries, int sp, uint2 e) {
+    stk[min(sp, lds_entries) * 64] = e;
+    if (sp >= lds_entries) ovf[(sp - lds_entries) * 64] = e;
+}
+__device__ __forceinline__ uint2 stack_pop(const uint2 *stk, const uint2 *ovf, int lds_entries, int sp) {
+    uint2 e = stk[min(sp, lds_entries) * 64];
+    if (sp >= lds_entries) e = ovf[(sp - lds_entries) * 64];
+    return e;
+}
+
+template <bool COUNT, int SRC, bool LOOP>
+__global__ void __launch_bounds__(256)
+k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, float4 *__restrict__ rad,
+        PathArrays pa, DevCounters *ctr) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the first lds_entries stack levels live in LDS, deeper ones (rare) in a per-wave global slab
+    const int lds_entries = (int)wk.lds_entries;
+    uint2 *stk = lds_stack + (size_t)wave * (lds_entries + 1) * 64 + lane;
+    uint2 *ovf = (uint2 *)wk.overflow_stack +
+                 ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * wk.overflow_entries) * 64 + lane;
+    const float4 *__restrict__ inner = (const float4 *)sc.inner;
+    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    constexpr uint32_t kReserve = 256;
+
+    // wave-uniform scheduling state
+    uint32_t src = blockIdx.x % wk.nsrc, res_lo = 0, res_hi = 0, tried = 0;
+    bool exhausted = false;
+    const uint32_t out_sub = blockIdx.x % kSubQueues;
+    // lane state
+    bool has = false, tdone = false, exact = false, is_ray = false;
+    Path P;
+    float ix = 0.f, iy = 0.f, iz = 0.f, best = 0.f, cur_near = 0.f;
+    int slot = -1, sp = 0;
+    uint32_t cur = 0;
+    Cnt c0 = {0, 0}, c1 = {0, 0};
+    Tally tl = {{0, 0}, {0, 0}, {0, 0}};
+    uint32_t overflow = 0;
+
+    auto start_traversal = [&]() {
+        ix = 1.0f / P.dx, iy = 1.0f / P.dy, iz = 1.0f / P.dz;  // Ray.h:10
+        exact = !(finite3(ix, iy, iz) && finite3(P.ox, P.oy, P.oz));
+        is_ray = (P.depth == 0) || finite3(P.dx, P.dy, P.dz);
+        best = 999999999.f;  // bvh.cpp:48
+        slot = -1;
+        sp = 0;
+        cur = sc.root_ref;
+        cur_near = -9999999.f;  // bvh.cpp:59
+        tdone = false;
+    };
+
+    for (;;) {
+        // ---- 1. shade the lanes whose traversal is finished ---------------------
+        {
+            const unsigned long long fin = __ballot(has && tdone);
+            const unsigned long long trav = __ballot(has && !tdone);
+            if (fin != 0 && ((uint32_t)__popcll(fin) >= wk.shade_min || trav == 0)) {
+                const bool shaded = has && tdone;
+                bool alive = false;
+                StepFlags fl = {false, false, false};
+                uint32_t depth0 = 0;
+                if (shaded) {
+                    depth0 = P.depth == 0 ? 1u : 0u;
+                    CastResult c;
+                    cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, best, slot, c);
+                    fl.was_ray = is_ray;
+                    alive = path_shade(fr.r2scale, P, c, fl);
+                    if (!alive) {
+                        rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
+                        has = false;
+                    }
+                }
+                tally_add(tl, fl, shaded, depth0);
+                if (LOOP) {
+                    if (shaded && alive) start_traversal();
+                } else {
+                    if (!queue_append_checked(qout, out_sub, alive, P)) overflow = 1;
+                    if (shaded && alive) has = false;
+                }
+            }
+        }
+        // ---- 2. refill idle lanes from the work source ---------------------------
+        {
+            const unsigned long long idle = __ballot(!has);
+            if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= wk.refill_min || idle == ~0ull)) {
+                for (;;) {
+                    if (res_lo == res_hi) {
+                        const uint32_t lim = SRC == 0   ? wk.band_items
+                                             : SRC == 1 ? min(wk.qin.counts[src * 32], wk.qin.sub_capacity)
+                                                        : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&wk.heads[src * 32], kReserve);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base >= lim) {
+                            src = (src + 1 == wk.nsrc) ? 0 : src + 1;
+                            if (++tried == wk.nsrc) {
+                                exhausted = true;
+                                break;
+                            }
+                            continue;
+                        }
+                        tried = 0;
+                        res_lo = base;
+                        res_hi = min(base + kReserve, lim);
+                    }
+                    const unsigned long long want = __ballot(!has);
+                    if (want == 0) break;
+                    const uint32_t avail = res_hi - res_lo;
+                    const uint32_t rank = (uint32_t)__popcll(want & lt_mask);
+                    const bool take = !has && rank < avail;
+                    const uint32_t item = res_lo + rank;
+                    res_lo += min((uint32_t)__popcll(want), avail);
+                    if (take) {
+                        bool valid = true;
+                        if (SRC == 0) {
+                            const uint32_t j = item / wk.band_slots;
+                            const uint32_t s_idx = src * wk.band_slots + (item - j * wk.band_slots);
+                            valid = s_idx < wk.n_active;
+                            if (valid) {
+                                const uint32_t lp = wk.active[s_idx];
+                                const uint32_t k = px.cursor[lp] + j;
+                                valid = k < fr.kmax;
+                                if (valid) {
+                                    primary_ray(fr, global_pixel(fr, lp), k, P.rng, P.dx, P.dy, P.dz);
+                                    P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz;
+                                                        P.ar = P.ag = P.ab = 0.f;
+                                    P.aw = -100.f;  // pathtracer.cpp:29
+                                    P.depth = 0;
+                                    P.dest = j * wk.n_pad + s_idx;
+                                }
+                            }
+                        } else if (SRC == 1) {
+                            path_load(wk.qin, src * wk.qin.sub_capacity + item, P);
+                            valid = P.depth != 0xFFFFFFFFu;  // dead slot left by an overflowing append
+                        } else {
+                            path_load_arrays(pa, wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item], P);
+                        }
+                        if (valid) {
+                            has = true;
+                            start_traversal();
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(has) == 0) break;
+        // ---- 3. one traversal action for the wave (bvh.cpp:61-134) -----------------
+        // Lanes sit either at an inner node or at a leaf triangle.  Executing both
+        // branches every iteration wastes most lanes on incoherent rays (a few lanes at
+        // leaves, the rest at inner nodes), so the wave votes: the triangle step runs when
+        // the leaf lanes are the majority (or at least leaf_min), else the inner step; the
+        // other lanes wait.  Each lane's own sequence of tests is unchanged.
+        const bool trav = has && !tdone;
+        const bool at_leaf = trav && (cur & kLeafBit) != 0;
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+        const uint32_t n_inner = (uint32_t)__popcll(__ballot(trav && !at_leaf));
+        bool need_next = false;  // this lane finished its node and must select the next one
+        bool carry = false;
+        if (n_leaf != 0 && (n_leaf >= n_inner || n_leaf >= wk.leaf_min)) {
+            if (at_leaf) {
+                // one triangle (triangle.cpp:4-54); the leaf ref itself carries the progress
+                const uint32_t ti = (cur & kLeafStartMask) * 3;
+                const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
+                if (COUNT) {
+                    if (P.depth == 0) c0.tris++;
+                    else c1.tris++;
+                }
+                const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+                float pvx, pvy, pvz;
+                cross3(P.dx, P.dy, P.dz, e2x, e2y, e2z, pvx, pvy, pvz);
+                const float det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
+                const bool parallel = fabsf(det) <= 9.99999993922529e-09f;
+                const float inv_det = 1.0f / det;
+                const float tx = P.ox - a.x, ty = P.oy - a.y, tz = P.oz - a.z;
+                const float u = dot3(tx, ty, tz, pvx, pvy, pvz) * inv_det;
+                const bool u_out = (u < 0.0f) || (u > 1.0f);
+                float qx, qy, qz;
+                cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+                const float v = dot3(P.dx, P.dy, P.dz, qx, qy, qz) * inv_det;
+                const bool v_out = (v < 0.0f) || (u + v > 1.0f);
+                const float dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+                const bool hit = !parallel && !u_out && !v_out && (dist > 0.0f);
+                if (hit && dist < best) {  // strict <: first tested wins ties (bvh.cpp:90)
+                    best = dist;
+                    slot = (int)(cur & kLeafStartMask);
+                }
+                const uint32_t left = ((cur >> kLeafCountShift) & 31u) - 1u;
+                if (left == 0) need_next = true;
+                else cur = kLeafBit | (left << kLeafCountShift) | ((cur & kLeafStartMask) + 1u);
+            }
+        } else if (n_inner != 0) {
+            if (trav && !at_leaf) {
+                const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2],
+                             q3 = inner[cur * 4 + 3];
+                if (COUNT) {
+                    if (P.depth == 0) c0.inner++;
+                    else c1.inner++;
+                }
+                float tn0, tn1;
+                bool h0, h1;
+                if (exact) {
+                    h0 = box_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, P.ox, P.oy, P.oz, ix, iy, iz, tn0);
+                    h1 = box_exact(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, P.ox, P.oy, P.oz, ix, iy, iz, tn1);
+                } else {
+                    h0 = box_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, P.ox, P.oy, P.oz, ix, iy, iz, tn0);
+                    h1 = box_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, P.ox, P.oy, P.oz, ix, iy, iz, tn1);
+                }
+                const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+                need_next = true;
+                if (h0 && h1) {
+                    const bool sw = tn1 < tn0;  // bvh.cpp:110
+                    const uint32_t other = sw ? lref : rref;
+                    const float no = sw ? tn0 : tn1;
+                    stack_push(stk, ovf, lds_entries, sp, make_uint2(other, __float_as_uint(no)));
+                    ++sp;
+                    cur = sw ? rref : lref;
+                    cur_near = sw ? tn1 : tn0;
+                    carry = true;
+                } else if (h0) {
+                    cur = lref;
+                    cur_near = tn0;
+                    carry = true;
+                } else if (h1) {
+                    cur = rref;
+                    cur_near = tn1;
+                    carry = true;
+                }
+            }
+        }
+        if (need_next) {
+            // next node: the carried child, else pop until an entry passes `near > t` (bvh.cpp:69)
+            if (carry && cur_near > best) carry = false;
+            while (!carry) {
+                if (sp == 0) {
+                    tdone = true;
+                    break;
+                }
+                --sp;
+                const uint2 e = stack_pop(stk, ovf, lds_entries, sp);
+                if (!(__uint_as_float(e.y) > best)) {
+                    cur = e.x;
+                    cur_near = __uint_as_float(e.y);
+                    carry = true;
+                }
+            }
+        }
+    }
+    tally_flush<COUNT>(ctr, tl, c0, c1);
+    if (__ballot(overflow != 0) != 0 && lane == 0) atomicAdd(&ctr->overflow, 1ull);
+}
+
+
+
+// ---------------------------------------------------------------------------
+// k_raygen — camera rays of one pass (pathtracer.cpp:251-280): ray of path
+// pid = j * n_pad + slot into rayA/rayB (depth 0).  Slots whose sample index is
+// past the pixel's last sample get depth = ~0 and are skipped downstream.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_raygen(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
+    const uint32_t total = wk.samples * wk.n_pad;
+    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < total; pid += gridDim.x * blockDim.x) {
+        const uint32_t j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
+        if (s_idx >= wk.n_active) continue;
+        uint32_t pid2, pixel, k;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        uint32_t depth = 0xFFFFFFFFu;
+        if (primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {
+            Rng rng;
+            primary_ray(fr, pixel, k, rng, dx, dy, dz);
+            depth = 0;
+        }
+        ((float4 *)pa.rayA)[pid] = make_float4(fr.px, fr.py, fr.pz, dx);
+        ((float4 *)pa.rayB)[pid] = make_float4(dy, dz, __uint_as_float(depth), 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_trace_q — the lean persistent traversal kernel of the split wavefront
+// (BVH::getIntersection only, bvh.cpp:47-145).  Lane state is one ray; lanes
+// refill themselves from the work source; the wave votes between the inner
+// step and the triangle step.  Writes hit[pid] = (t, leaf slot).
+//   SRC 0: primary rays, generated from (pixel, sample) — origin is uniform
+//   SRC 1: bounce rays of the queued path ids, read from rayA/rayB
+// ---------------------------------------------------------------------------
+template <bool COUNT, int SRC>
+__global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD)
+k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, DevCounters *ctr) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const int lds_entries = (int)wk.lds_entries;
+    uint2 *stk = lds_stack + (size_t)wave * (lds_entries + 1) * 64 + lane;
+    uint2 *ovf = (uint2 *)wk.overflow_stack +
+                 ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * wk.overflow_entries) * 64 + lane;
+    const float4 *__restrict__ inner = (const float4 *)sc.inner;
+    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    float2 *__restrict__ hit_out = (float2 *)pa.hit;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    constexpr uint32_t kReserve = 256;
+    constexpr int kActionsPerCheck = 8;  // traversal actions between two scheduling checks
+    const uint32_t nsrc = wk.nsrc, refill_min = wk.refill_min, leaf_min = wk.leaf_min;
+    const uint32_t band_slots = wk.band_slots, band_items = wk.band_items;
+    const uint32_t root_ref = sc.root_ref;
+
+    // wave-uniform scheduling state (kept in SGPRs through readfirstlane)
+    uint32_t src = blockIdx.x % nsrc, res_lo = 0, res_hi = 0, tried = 0;
+    bool exhausted = false;
+    // lane state: one ray
+    bool has = false, exact = false, counted = false;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    float ix = 0.f, iy = 0.f, iz = 0.f, best = 0.f, cur_near = 0.f;
+    int slot = -1, sp = 0;
+    uint32_t cur = 0, pid = 0;
+    Cnt cn = {0, 0};
+
+    for (;;) {
+        // ---- refill idle lanes -------------------------------------------------------
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has);
+        if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= refill_min || idle == ~0ull)) {
+            for (;;) {
+                if (res_lo == res_hi) {
+                    const uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&wk.heads[src * 32], kReserve);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= lim) {
+                        src = (src + 1 == nsrc) ? 0 : src + 1;
+                        if (++tried == nsrc) {
+                            exhausted = true;
+                            break;
+                        }
+                        continue;
+                    }
+                    tried = 0;
+                    res_lo = base;
+                    res_hi = min(base + kReserve, lim);
+                }
+                const unsigned long long want = __builtin_amdgcn_ballot_w64(!has);
+                if (want == 0) break;
+                const uint32_t avail = res_hi - res_lo;
+                const uint32_t rank = (uint32_t)__popcll(want & lt_mask);
+                const bool take = !has && rank < avail;
+                const uint32_t item = res_lo + rank;
+                res_lo = __builtin_amdgcn_readfirstlane(res_lo + min((uint32_t)__popcll(want), avail));
+                if (take) {
+                    bool valid = true;
+                    if (SRC == 0) {
+                        // band-local item -> path id; the ray was written by k_raygen
+                        const uint32_t j = item / band_slots;
+                        const uint32_t s_idx = src * band_slots + (item - j * band_slots);
+                        valid = s_idx < wk.n_active;
+                        pid = j * wk.n_pad + s_idx;
+                    } else {
+                        pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
+                    }
+                    if (valid) {
+                        const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
+                        ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
+                        const uint32_t depth = __float_as_uint(b.z);
+                        valid = depth != 0xFFFFFFFFu;  // k_raygen marks sample slots past the pixel's last sample
+                        counted = (depth == 0u) || finite3(dx, dy, dz);
+                    }
+                    if (valid) {
+                        has = true;
+                        ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // Ray.h:10
+                        exact = !(finite3(ix, iy, iz) && finite3(ox, oy, oz));
+                        best = 999999999.f;  // bvh.cpp:48
+                        slot = -1;
+                        sp = 0;
+                        cur = root_ref;
+                        cur_near = -9999999.f;  // bvh.cpp:59
+                    }
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(has) == 0) break;
+        // ---- traversal actions, each chosen by vote (see k_paths) ----------------------
+        for (int act = 0; act < kActionsPerCheck; ++act) {
+            const bool at_leaf = has && (cur & kLeafBit) != 0;
+            const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(at_leaf);
+            const unsigned long long m_inner = __builtin_amdgcn_ballot_w64(has && !at_leaf);
+            if ((m_leaf | m_inner) == 0) break;
+            const uint32_t n_leaf = (uint32_t)__popcll(m_leaf), n_inner = (uint32_t)__popcll(m_inner);
+            bool need_next = false, carry = false;
+            if (n_leaf >= n_inner || n_leaf >= leaf_min) {
+                if (at_leaf) {
+                    const uint32_t ti = (cur & kLeafStartMask) * 3;
+                    const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
+                    if (COUNT && counted) cn.tris++;
+                    const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+                    float pvx, pvy, pvz;
+                    cross3(dx, dy, dz, e2x, e2y, e2z, pvx, pvy, pvz);
+                    const float det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
+                    const bool parallel = fabsf(det) <= 9.99999993922529e-09f;
+                    const float inv_det = 1.0f / det;
+                    const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+                    const float u = dot3(tx, ty, tz, pvx, pvy, pvz) * inv_det;
+                    const bool u_out = (u < 0.0f) || (u > 1.0f);
+                    float qx, qy, qz;
+                    cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+                    const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+                    const bool v_out = (v < 0.0f) || (u + v > 1.0f);
+                    const float dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+                    const bool hit = !parallel && !u_out && !v_out && (dist > 0.0f);
+                    if (hit && dist < best) {  // strict <: first tested wins ties (bvh.cpp:90)
+                        best = dist;
+                        slot = (int)(cur & kLeafStartMask);
+                    }
+                    const uint32_t left = ((cur >> kLeafCountShift) & 31u) - 1u;
+                    if (left == 0) need_next = true;
+                    else cur = kLeafBit | (left << kLeafCountShift) | ((cur & kLeafStartMask) + 1u);
+                }
+            } else {
+                if (has && !at_leaf) {
+                    const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2],
+                                 q3 = inner[cur * 4 + 3];
+                    if (COUNT && counted) cn.inner++;
+                    float tn0, tn1;
+                    bool h0, h1;
+                    if (exact) {
+                        h0 = box_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, tn0);
+                        h1 = box_exact(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, tn1);
+                    } else {
+                        h0 = box_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, tn0);
+                        h1 = box_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, tn1);
+                    }
+                    const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+                    need_next = true;
+                    if (h0 && h1) {
+                        const bool sw = tn1 < tn0;  // bvh.cpp:110
+                        stack_push(stk, ovf, lds_entries, sp,
+                                   make_uint2(sw ? lref : rref, __float_as_uint(sw ? tn0 : tn1)));
+                        ++sp;
+                        cur = sw ? rref : lref;
+                        cur_near = sw ? tn1 : tn0;
+                        carry = true;
+                    } else if (h0) {
+                        cur = lref;
+                        cur_near = tn0;
+                        carry = true;
+                    } else if (h1) {
+                        cur = rref;
+                        cur_near = tn1;
+                        carry = true;
+                    }
+                }
+            }
+            if (need_next) {
+                if (carry && cur_near > best) carry = false;  // bvh.cpp:69
+                while (!carry) {
+                    if (sp == 0) {
+                        hit_out[pid] = make_float2(best, __int_as_float(slot));
+                        has = false;
+                        break;
+                    }
+                    --sp;
+                    const uint2 e = stack_pop(stk, ovf, lds_entries, sp);
+                    if (!(__uint_as_float(e.y) > best)) {
+                        cur = e.x;
+                        cur_near = __uint_as_float(e.y);
+                        carry = true;
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        const uint32_t iv = wave_sum(cn.inner), tt = wave_sum(cn.tris);
+        if (lane == 0) {
+            const int st = SRC == 0 ? 0 : 1;
+            if (iv) atomicAdd(&ctr->stage[st].inner_visits, (unsigned long long)iv);
+            if (tt) atomicAdd(&ctr->stage[st].tri_tests, (unsigned long long)tt);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_shade — the wide shading kernel of the split wavefront: the part of
+// MeshEngine::RayCast after the BVH query (triangle normal, sphere table,
+// meshEngine.cpp:365-508) and one iteration of Radiance's loop
+// (pathtracer.cpp:36-196), one lane per path, then wave-ballot compaction of
+// the surviving path ids.
+//   SRC 0: depth-0 steps; the camera ray and the RNG stream are regenerated
+//          from (pixel, sample) instead of being stored by the trace kernel
+//   SRC 1: queued path ids; ray, RNG and accumulated colour come from the arrays
+// ---------------------------------------------------------------------------
+template <int SRC>
+__global__ void __launch_bounds__(256)
+k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, IdQueue qout, uint32_t max_chunks,
+        DevCounters *ctr) {
+    const float2 *__restrict__ hits = (const float2 *)pa.hit;
+    float4 *__restrict__ rad = (float4 *)pa.rad;
+    Tally tl = {{0, 0}, {0, 0}, {0, 0}};
+    const uint32_t items = SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        bool run;
+        uint32_t pid = 0;
+        Path P;
+        if (SRC == 0) {
+            pid = item * blockDim.x + threadIdx.x;
+            const uint32_t j = pid / wk.n_pad;
+            uint32_t pixel = 0, k = 0, pid2;
+            run = j < wk.samples && primary_item(fr, wk, px, j, pid - j * wk.n_pad, pid2, pixel, k);
+            if (run) {
+                // the ray comes from k_raygen; the stream is re-keyed and its two jitter draws skipped
+                ray_load(pa, pid, P);
+                rng_init(P.rng, fr.seed, pixel, k);
+                (void)rng_next(P.rng);
+                (void)rng_next(P.rng);
+                P.ar = P.ag = P.ab = 0.f;
+                P.aw = -100.f;  // pathtracer.cpp:29
+            }
+        } else {
+            const uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
+            const uint32_t pos = chunk * blockDim.x + threadIdx.x;
+            run = pos < min(wk.qids.counts[sub * 32], wk.qids.sub_capacity);
+            if (run) {
+                pid = wk.qids.ids[(size_t)sub * wk.qids.sub_capacity + pos];
+                path_load_arrays(pa, pid, P);
+            }
+        }
+        StepFlags fl = {false, false, false};
+        bool alive = false;
+        uint32_t depth0 = 0;
+        if (run) {
+            P.dest = pid;
+            depth0 = P.depth == 0 ? 1u : 0u;
+            fl.was_ray = depth0 ? true : finite3(P.dx, P.dy, P.dz);
+            const float2 h = hits[pid];
+            CastResult c;
+            cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c);
+            alive = path_shade(fr.r2scale, P, c, fl);
+            rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
+            if (alive) {
+                ray_store(pa, pid, P);
+                rng_store(pa, pid, P.rng);
+            }
+        }
+        tally_add(tl, fl, run, depth0);
+        id_append(qout, item % kSubQueues, alive, pid);
+    }
+    const Cnt none = {0, 0};
+    tally_flush<false>(ctr, tl, none, none);
+}
+
+// explicit camera rays for vmx_radiance (split wavefront): path i keyed (seed, i, 0), jitter draws skipped
+__global__ void k_radiance_init_ids(const float *__restrict__ o, const float *__restrict__ d, uint32_t n,
+                                    uint64_t seed, PathArrays pa, IdQueue qout) {
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        const bool run = i < n;
+        if (run) {
+            Path P;
+            rng_init(P.rng, seed, i, 0);
+            (void)rng_next(P.rng);
+            (void)rng_next(P.rng);
+            P.ox = o[i * 3], P.oy = o[i * 3 + 1], P.oz = o[i * 3 + 2];
+            P.dx = d[i * 3], P.dy = d[i * 3 + 1], P.dz = d[i * 3 + 2];
+            P.depth = 0;
+            ray_store(pa, i, P);
+            rng_store(pa, i, P.rng);
+            ((float4 *)pa.rad)[i] = make_float4(0.f, 0.f, 0.f, -100.f);
+        }
+        id_append(qout, (base / blockDim.x) % kSubQueues, run, i);
+    }
+}
+
 // per-pixel accumulation in sample order + early stop + pixel write (pathtracer.cpp:282-324)
 __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, uint32_t n_active,
                           uint32_t n_pad, uint32_t samples, const float4 *__restrict__ rad, PixelStateDev px,
                           unsigned int *__restrict__ next_active, unsigned int *next_count,
                           float *__restrict__ out, DevCounters *ctr) {
-    __shared__ unsigned int s_keep, s_base, s_taken, s_disc, s_done;
-    if (threadIdx.x == 0) s_keep = 0, s_taken = 0, s_disc = 0, s_done = 0;
+    __shared__ unsigned int s_keep, s_base, s_taken, s_disc, s_done, s_brk;
+    if (threadIdx.x == 0) s_keep = 0, s_taken = 0, s_disc = 0, s_done = 0, s_brk = 0;
     __syncthreads();
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
-    uint32_t lp = 0, taken = 0, disc = 0, done = 0;
+    uint32_t lp = 0, taken = 0, disc = 0, done = 0, brk = 0;
     if (slot < n_active) {
         lp = active[slot];
         float4 acc = ((float4 *)px.accum)[lp];
@@ -820,6 +1529,7 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
                     next = (k / fr.quarter + 1u) * fr.quarter;  // break the innermost loop only
                     const uint32_t last = cursor + samples < fr.kmax ? cursor + samples : fr.kmax;
                     disc = last - (k + 1);
+                    brk = 1;
                     break;
                 }
             }
@@ -846,9 +1556,11 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
     if (taken) atomicAdd(&s_taken, taken);
     if (disc) atomicAdd(&s_disc, disc);
     if (done) atomicAdd(&s_done, 1u);
+    if (brk) atomicAdd(&s_brk, 1u);
     __syncthreads();
     if (threadIdx.x == 0) {
         s_base = s_keep ? atomicAdd(next_count, s_keep) : 0u;
+        if (s_brk) atomicAdd(next_count + 1, s_brk);
         if (s_taken) atomicAdd(&ctr->samples, (unsigned long long)s_taken);
         if (s_disc) atomicAdd(&ctr->discarded, (unsigned long long)s_disc);
         if (s_done) atomicAdd(&ctr->pixels_done, (unsigned long long)s_done);
@@ -957,6 +1669,112 @@ int launch_bounce(const SceneDev &sc, float r2scale, QueueDev qin, uint32_t max_
     }
 #undef VMX_GO
     return launch_status();
+}
+
+int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, QueueDev qout,
+                 void *rad, DevCounters *counters, bool count, bool from_queue, bool loop_to_end, LaunchCfg cfg,
+                 void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(cfg.grid), b(cfg.block);
+#define VMX_GO(C, S, L)                                                                                   \
+    hipLaunchKernelGGL((k_paths<C, S, L>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)rad, pa, counters)
+    // instantiated forms: primary source following every path to its end (pipeline 1)
+    PathArrays pa{};
+    (void)from_queue;
+    (void)loop_to_end;
+    if (count) VMX_GO(true, 0, true);
+    else VMX_GO(false, 0, true);
+#undef VMX_GO
+    return launch_status();
+}
+
+int launch_tail(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathArrays pa, DevCounters *counters,
+                bool count, LaunchCfg cfg, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(cfg.grid), b(cfg.block);
+    PixelStateDev px{nullptr, nullptr, nullptr};
+    QueueDev qout{};
+    if (count)
+        hipLaunchKernelGGL((k_paths<true, 2, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)pa.rad, pa,
+                           counters);
+    else
+        hipLaunchKernelGGL((k_paths<false, 2, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)pa.rad,
+                           pa, counters);
+    return launch_status();
+}
+
+int launch_raygen(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream) {
+    const uint64_t total = (uint64_t)wk.samples * wk.n_pad;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 32u);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(256), 0, (hipStream_t)stream, fr, wk, px, pa);
+    return launch_status();
+}
+
+int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
+                   DevCounters *counters, bool count, bool from_queue, LaunchCfg cfg, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(cfg.grid), b(cfg.block);
+#define VMX_GO(C, S) hipLaunchKernelGGL((k_trace_q<C, S>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, pa, counters)
+    if (count) {
+        if (from_queue) VMX_GO(true, 1);
+        else VMX_GO(true, 0);
+    } else {
+        if (from_queue) VMX_GO(false, 1);
+        else VMX_GO(false, 0);
+    }
+#undef VMX_GO
+    return launch_status();
+}
+
+int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks) {
+    int a = 0, b = 0;
+    hipError_t e;
+    if (count) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 0>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_q<true, 1>, (int)block, lds_bytes);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<false, 0>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_q<false, 1>, (int)block, lds_bytes);
+    }
+    if (blocks) *blocks = a < b ? a : b;
+    return (int)e;
+}
+
+int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
+                 IdQueue qout, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t items = from_queue ? (uint64_t)max_chunks * kSubQueues
+                                      : ((uint64_t)wk.samples * wk.n_pad + 255) / 256;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(items, 256u * 16u);
+    if (grid == 0) grid = 1;
+    if (from_queue)
+        hipLaunchKernelGGL((k_shade<1>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters);
+    else
+        hipLaunchKernelGGL((k_shade<0>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters);
+    return launch_status();
+}
+
+int launch_radiance_init_ids(const float *o, const float *d, uint32_t n, uint64_t seed, PathArrays pa, IdQueue qout,
+                             void *stream) {
+    uint32_t grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_radiance_init_ids, dim3(grid), dim3(256), 0, (hipStream_t)stream, o, d, n, seed, pa, qout);
+    return launch_status();
+}
+
+int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks) {
+    int a = 0, b = 0;
+    hipError_t e;
+    if (count) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<true, 0, true>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<true, 2, true>, (int)block, lds_bytes);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<false, 0, true>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<false, 2, true>, (int)block, lds_bytes);
+    }
+    if (blocks) *blocks = a < b ? a : b;
+    return (int)e;
 }
 
 int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,

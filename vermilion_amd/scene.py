@@ -30,7 +30,8 @@ def make_camera(position, rotation_deg, width, height, spp, back_distance=6.0, b
 
 
 def make_opts(seed=1, early_stop=True, sampling=L.VMX_SAMPLING_PARITY, rank=0, world=1, stripe_rows=16,
-              samples_per_batch=0, collect_counters=False, pipeline=0, max_paths=0, tail_threshold=0):
+              samples_per_batch=0, collect_counters=False, pipeline=0, max_paths=0, tail_threshold=0,
+              refill_min=0, shade_min=0, leaf_min=0, lds_entries=0):
     o = L.Opts()
     o.seed = int(seed)
     o.early_stop = 1 if early_stop else 0
@@ -38,9 +39,13 @@ def make_opts(seed=1, early_stop=True, sampling=L.VMX_SAMPLING_PARITY, rank=0, w
     o.rank, o.world, o.stripe_rows = int(rank), int(world), int(stripe_rows)
     o.samples_per_batch = int(samples_per_batch)
     o.collect_counters = 1 if collect_counters else 0
-    o.reserved[0] = int(pipeline)      # 0 wavefront, 1 every lane follows its path to the end
+    o.reserved[0] = int(pipeline)      # 0/1 refill kernels (wavefront / to-the-end), 2/3 first-generation kernels
     o.reserved[1] = int(max_paths)     # paths in flight per pass (0 -> 16M)
     o.reserved[2] = int(tail_threshold)
+    o.reserved[3] = int(refill_min)    # k_paths: refill when this many lanes idle (0 -> 16)
+    o.reserved[4] = int(shade_min)     # k_paths: shade when this many lanes finished (0 -> 16)
+    o.reserved[5] = int(leaf_min)      # k_paths: triangle step when this many lanes sit at a leaf (0 -> 16)
+    o.reserved[6] = int(lds_entries)   # k_paths: stack levels kept in LDS (0 -> 16), deeper ones spill to HBM
     return o
 
 
