@@ -35,9 +35,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def alg_bytes(stage):
-    """B_ray = 64*N_inner + 48*N_tri + 48 + 64*[tri hit] + 96*[path continues]"""
+    """SURVEY.md §8(d), whole path: B_ray = 64*N_inner + 48*N_tri + 48 + 64*[tri hit] + 96*[path continues]"""
     return (64 * stage["inner_visits"] + 48 * stage["tri_tests"] + 48 * stage["rays"] + 64 * stage["tri_hits"]
             + 96 * stage["continued"])
+
+
+def trace_alg_bytes(stage):
+    """the traversal kernel's share of it: node records + triangle records + ray read (32 B) + hit write (8 B)"""
+    return 64 * stage["inner_visits"] + 48 * stage["tri_tests"] + 40 * stage["rays"]
 
 
 def main():
@@ -124,14 +129,14 @@ def main():
     if rank == 0:
         prim_ms = sum(s["primary"]["ms"] for s in stats)
         prim_launches = sum(s["primary"]["launches"] for s in stats)
-        bytes_per_launch = alg_bytes(cst["primary"]) / max(cst["primary"]["launches"], 1)
+        bytes_per_launch = trace_alg_bytes(cst["primary"]) / max(cst["primary"]["launches"], 1)
         avg_ms = prim_ms / max(prim_launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_primary_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_trace_q_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         total_rays_frame = cst["rays_primary"] + cst["rays_secondary"]
@@ -157,7 +162,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_primary (raygen + BVH/sphere RayCast + Radiance step, depth 0)",
+                "kernel": "k_trace_q<SRC=primary> (persistent BVH traversal of the depth-0 rays)",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -166,13 +171,15 @@ def main():
                 "alg_bytes_per_launch": int(bytes_per_launch),
                 "avg_launch_ms": round(avg_ms, 4),
                 "launches_per_step": prim_launches // max(args.steps, 1),
-                "alg_bytes_per_ray": round(alg_bytes(cst["primary"]) / max(cst["primary"]["rays"], 1), 1),
+                "alg_bytes_per_ray": round(trace_alg_bytes(cst["primary"]) / max(cst["primary"]["rays"], 1), 1),
+                "alg_bytes_per_ray_whole_path": round(alg_bytes(cst["primary"]) / max(cst["primary"]["rays"], 1), 1),
                 "inner_visits_per_ray": round(cst["primary"]["inner_visits"] / max(cst["primary"]["rays"], 1), 2),
                 "tri_tests_per_ray": round(cst["primary"]["tri_tests"] / max(cst["primary"]["rays"], 1), 2),
             },
             "stage_ms_per_step": {
-                "primary": round(prim_ms / args.steps, 3),
-                "bounce": round(sum(s["bounce"]["ms"] for s in stats) / args.steps, 3),
+                "primary_trace": round(prim_ms / args.steps, 3),
+                "bounce_trace_and_tail": round(sum(s["bounce"]["ms"] for s in stats) / args.steps, 3),
+                "shade": round(sum(s["shade"]["ms"] for s in stats) / args.steps, 3),
                 "device_total": round(sum(s["ms_device"] for s in stats) / args.steps, 3),
             },
             "whole_frame_alg_GBs": round((alg_bytes(cst["primary"]) + alg_bytes(cst["bounce"])) / (ms_per_step * 1e-3) / 1e9, 1)

@@ -37,7 +37,7 @@ def test_full_size_frame_invariants(sponza):
     assert sa["samples"] == 1920 * 1080 * 16 == sa["rays_primary"]
     assert np.all(a[:, :, :3] >= 0) and np.all(a[:, :, :3] <= 1) and np.all(np.isfinite(a))
     # scheduling must not change a single bit
-    for kw in (dict(samples_per_batch=3), dict(pipeline=1), dict(pipeline=2), dict(pipeline=3), dict(tail_threshold=1),
+    for kw in (dict(samples_per_batch=3), dict(pipeline=1), dict(pipeline=2), dict(pipeline=3), dict(pipeline=4), dict(tail_threshold=1),
                dict(max_paths=1 << 20), dict(refill_min=1, shade_min=1), dict(refill_min=64, shade_min=64),
                dict(refill_min=5, shade_min=40)):
         b, sb = sponza.render(cam, va.make_opts(seed=1, early_stop=False, **kw))
@@ -45,7 +45,7 @@ def test_full_size_frame_invariants(sponza):
         assert sb["rays_secondary"] == sa["rays_secondary"]
     # early stop: the reference's sample-count pattern (one stratum at a time), same rays twice
     e1, s1 = sponza.render(cam, va.make_opts(seed=1, early_stop=True))
-    e2, s2 = sponza.render(cam, va.make_opts(seed=1, early_stop=True, pipeline=1))
+    e2, s2 = sponza.render(cam, va.make_opts(seed=1, early_stop=True, pipeline=4))
     assert np.array_equal(bits(e1), bits(e2)) and s1["rays_primary"] == s2["rays_primary"]
     assert set(np.unique(e1[:, :, 4])).issubset({7.0, 10.0, 13.0, 16.0})
     dark = e1[:, :, :3].sum(-1) == 0

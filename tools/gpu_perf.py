@@ -25,6 +25,7 @@ def main():
         if "m" in extra: kw["pipeline"] = 1
         if "o" in extra: kw["pipeline"] = 2
         if "O" in extra: kw["pipeline"] = 3
+        if "S" in extra: kw["pipeline"] = 4
         if "c" in extra: kw["collect_counters"] = True
         if os.environ.get("REFILL"): kw["refill_min"] = int(os.environ["REFILL"])
         if os.environ.get("SHADE"): kw["shade_min"] = int(os.environ["SHADE"])

@@ -4,7 +4,7 @@
 set -o pipefail
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-ARGS="${BENCH_ARGS:---steps 1 --warmup 0 --spp 64 --no-cpu-baseline}"
+ARGS="${BENCH_ARGS:---steps 1 --warmup 0 --no-cpu-baseline}"
 TAG=${TAG:-r01}
 cd /tmp
 i=0

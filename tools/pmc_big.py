@@ -17,7 +17,8 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}_*"))):
             k = m.group(1)
             ms = dur.get(r["Dispatch_Id"], 0)
             grid = int(r["Grid_Size"]) if "Grid_Size" in r else 0
-            if k.startswith("k_primary<false") and ms > 3.0 or k == "k_bounce<false, false>" and ms > 1.0:
+            if (k.startswith("k_trace_q<false, 0>") and ms > 10.0) or (k == "k_trace_q<false, 1>" and ms > 2.0) \
+                    or (k.startswith("k_shade<0>") and ms > 2.0):
                 res[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 res[k]["_ms_" + r["Counter_Name"]].append(ms)
 out = {}

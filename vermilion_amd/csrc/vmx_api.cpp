@@ -475,11 +475,13 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     //   0 split wavefront: k_trace_q + k_shade + id compaction (default)
     //   1 k_paths: refilling lanes keep their path to its end (no queues)
     //   2 first-generation k_primary/k_bounce wavefront   3 k_primary following every path to the end
+    //   4 split wavefront for every pass (form 0 hands passes of fewer than 4 M paths to form 1's
+    //     kernel, which needs no per-generation host round trip)
     const uint32_t pipeline = opts->reserved[0];
-    if (pipeline > 3) return fail(VMX_ERR_INVALID, "unknown pipeline form");
-    const bool split = pipeline == 0;
-    const bool refill = pipeline == 1;
-    const bool mega = pipeline == 1 || pipeline == 3;
+    if (pipeline > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    const bool split_any = pipeline == 0 || pipeline == 4;
+    const bool legacy = pipeline >= 2 && pipeline <= 3;
+    constexpr uint64_t kHybridPaths = 4ull << 20;
     const Tuning tn = make_tuning(sc, opts);
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
@@ -513,15 +515,16 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     PathArrays pa{};
     IdQueue qi[2];
     int tb = 1;
-    if (split) {
+    if (split_any) {
         rc = ensure_paths(sc, (size_t)n_pad_max * smax, pa, qi);
         if (rc) return rc;
         HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_entries + 1) * 512, count, &tb));
         if (tb < 1) return fail(VMX_ERR_HIP, "trace kernel does not fit on a CU");
-    } else {
+    } else if (legacy) {
         rc = ensure_queues(sc, sub_cap, q);
         if (rc) return rc;
     }
+    if (ws.heads.ensure(kSubQueues * 32)) return fail(VMX_ERR_NOMEM, "work heads");
     if (ws.rad.ensure((size_t)n_pad_max * smax * 16) || ws.accum.ensure((size_t)npix * 16) ||
         ws.count.ensure(npix) || ws.cursor.ensure(npix) || ws.active[0].ensure(npix) ||
         ws.active[1].ensure(npix) || ws.next_count.ensure(32) || ws.counters.ensure(1))
@@ -579,6 +582,10 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         }
         const uint32_t n_pad = (n_active + 63u) & ~63u;
         const uint32_t tiles8 = (((n_pad + sc->block - 1) / sc->block) + 7u) & ~7u;
+        // the form this pass runs in
+        const bool split = pipeline == 4 || (pipeline == 0 && (uint64_t)n_pad * S >= kHybridPaths);
+        const bool refill = pipeline == 1 || (pipeline == 0 && !split);
+        const bool mega = refill || pipeline == 3;
         if (!mega && !split) HIP_TRY(hipMemsetAsync(q[0].counts, 0, kSubQueues * 32 * 4, s));
         TimedLaunch tl{ws.events.get(), ws.events.get(), 0};
         if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
