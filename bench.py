@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (frames travel through host memory)")
+    ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (rehearsal)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -68,15 +71,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = args.device if args.device >= 0 else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     gen, camf = scenes.SCENES[args.scene]
     pos, nrm, uv = gen()
-    sc = va.Scene(pos, nrm, uv, device=local_rank)
+    sc = va.Scene(pos, nrm, uv, device=dev_index)
     desc = sc.describe()
     c = camf()
     W, H, spp = args.width, args.height, args.spp
@@ -90,7 +97,8 @@ def main():
         opts = va.make_opts(seed=args.seed, early_stop=early_stop, sampling=va.VMX_SAMPLING_PARITY, rank=rank,
                             world=world, stripe_rows=stripe, collect_counters=counters)
         st = sc.render_device(cam, opts, local.data_ptr(), stream)
-        frame = vdist.gather_frame(local, W, H, stripe, rank, world, dst=0)
+        src = local if args.backend == "nccl" or world == 1 else local.cpu()
+        frame = vdist.gather_frame(src, W, H, stripe, rank, world, dst=0)
         return st, frame
 
     def sync():
@@ -106,9 +114,10 @@ def main():
         dt = time.perf_counter() - t0
         rays = float(sum(s["rays_primary"] + s["rays_secondary"] for s in stats))
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            rdev = dev if args.backend == "nccl" else torch.device("cpu")
+            t = torch.tensor([dt], dtype=torch.float64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            r = torch.tensor([rays], dtype=torch.float64, device=dev)
+            r = torch.tensor([rays], dtype=torch.float64, device=rdev)
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
             dt, rays = float(t.item()), float(r.item())
         return dt, rays, stats
@@ -134,7 +143,7 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1 and (W, H, spp, args.scene) == (1920, 1080, 256, "sponza260k"):
             try:
                 traffic = json.load(open(tpath)).get("k_trace_q_hbm_bytes_per_launch")
             except Exception:
