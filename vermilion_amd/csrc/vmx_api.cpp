@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -299,17 +300,20 @@ int run_queue(vmx_scene *sc, float r2scale, QueueDev q[2], int cur, void *rad, D
 }
 
 struct Tuning {
-    uint32_t refill_min, shade_min, leaf_min, lds_entries, tail_threshold;
+    uint32_t refill_min, refill_primary, shade_min, leaf_min, lds_entries, tail_threshold;
 };
 
 Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     Tuning tn;
+    // coherent camera rays do best when a wave starts 64 of them together; incoherent bounce rays
+    // when finished lanes are replaced early (measured: 64 / 16)
     tn.refill_min = o->reserved[3] ? o->reserved[3] : 16u;
+    tn.refill_primary = o->reserved[3] ? o->reserved[3] : 64u;
     tn.shade_min = o->reserved[4] ? o->reserved[4] : 16u;
     tn.leaf_min = o->reserved[5] ? o->reserved[5] : 16u;
     const uint32_t cap = o->reserved[6] ? o->reserved[6] : 10u;  // 11 x 512 B per wave: 28 waves/CU fit in 160 KiB
     tn.lds_entries = std::min(sc->dev.stack_entries, cap);
-    tn.tail_threshold = o->reserved[2] ? o->reserved[2] : (256u << 10);
+    tn.tail_threshold = o->reserved[2] ? o->reserved[2] : (512u << 10);
     return tn;
 }
 
@@ -481,7 +485,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     if (pipeline > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
     const bool split_any = pipeline == 0 || pipeline == 4;
     const bool legacy = pipeline >= 2 && pipeline <= 3;
-    constexpr uint64_t kHybridPaths = 4ull << 20;
+    const uint64_t kHybridPaths = std::getenv("VMX_HYBRID") ? std::strtoull(std::getenv("VMX_HYBRID"), nullptr, 10) : (4ull << 20);
     const Tuning tn = make_tuning(sc, opts);
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
@@ -594,7 +598,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             std::memset(&wk, 0, sizeof(wk));
             wk.heads = ws.heads.p;
             wk.nsrc = 8;
-            wk.refill_min = tn.refill_min, wk.shade_min = tn.shade_min;
+            wk.refill_min = tn.refill_primary, wk.shade_min = tn.shade_min;
             wk.active = ws.active[cur_list].p;
             wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S;
             wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;

@@ -1230,6 +1230,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
     const uint32_t nsrc = wk.nsrc, refill_min = wk.refill_min, leaf_min = wk.leaf_min;
     const uint32_t band_slots = wk.band_slots, band_items = wk.band_items;
     const uint32_t root_ref = sc.root_ref;
+    const bool no_vote = leaf_min == 0xFFFFFFFFu;
 
     // wave-uniform scheduling state (kept in SGPRs through readfirstlane)
     uint32_t src = blockIdx.x % nsrc, res_lo = 0, res_hi = 0, tried = 0;
@@ -1311,7 +1312,10 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
             if ((m_leaf | m_inner) == 0) break;
             const uint32_t n_leaf = (uint32_t)__popcll(m_leaf), n_inner = (uint32_t)__popcll(m_inner);
             bool need_next = false, carry = false;
-            if (n_leaf >= n_inner || n_leaf >= leaf_min) {
+            // leaf_min == 0xFFFFFFFF: no vote, both steps every iteration (coherent camera rays)
+            const bool tri_turn = no_vote ? n_leaf != 0 : (n_leaf >= n_inner || n_leaf >= leaf_min);
+            const bool inner_turn = no_vote ? n_inner != 0 : !tri_turn;
+            if (tri_turn) {
                 if (at_leaf) {
                     const uint32_t ti = (cur & kLeafStartMask) * 3;
                     const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
@@ -1339,7 +1343,8 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                     if (left == 0) need_next = true;
                     else cur = kLeafBit | (left << kLeafCountShift) | ((cur & kLeafStartMask) + 1u);
                 }
-            } else {
+            }
+            if (inner_turn) {
                 if (has && !at_leaf) {
                     const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2],
                                  q3 = inner[cur * 4 + 3];
