@@ -173,6 +173,15 @@ int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32
                      const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size,
                      int device, vmx_scene **out);
 int vmx_scene_destroy(vmx_scene *scene);
+/*
+ * Replaces MeshEngine::bindTexture (meshEngine.cpp:74-93) minus the OpenImageIO read: `data` is the
+ * float image bindTexture would hand to VermiTexture (height rows of width texels of `channels`
+ * floats, 1..4 channels, width/height <= 65535 as VermiTexture stores uint16_t).  Only the FIRST
+ * bound texture is ever sampled by the path tracer (pathtracer.cpp:63-66: boundTextures[0], wrap
+ * + nearest, meshEngine.cpp:21-46); later calls are counted and otherwise ignored, as there.
+ */
+int vmx_scene_bind_texture(vmx_scene *scene, const float *data, uint32_t width, uint32_t height,
+                           uint32_t channels);
 int vmx_scene_describe(const vmx_scene *scene, vmx_scene_desc *out);
 /*
  * Host-side BVH topology in the reference's flat layout (bvh.h:11-14): per
@@ -228,6 +237,17 @@ int vmx_render_device(const vmx_scene *scene, const vmx_camera *cam, const vmx_o
 int vmx_assemble_device(const void *d_gathered, uint64_t rank_stride_floats, uint32_t width,
                         uint32_t height, uint32_t stripe_rows, uint32_t world, void *d_frame,
                         int device, void *stream);
+
+/* ---- frame output (the step after the path; replaces the conversion loop of
+ * Camera::saveFrame, core/camera/camera.cpp:140-175, for the default RGBAZ mode) ------------ */
+/*
+ * rgba8[p*4 + c] = (unsigned char)floor(frame[p*5 + c] * 255)   c = 0..3   (camera.cpp:159-162)
+ * depth[p]       = frame[p*5 + 4]                                          (camera.cpp:163)
+ * All three pointers are DEVICE memory on `device`; depth may be NULL.  The PNG/EXR encoding
+ * (OpenImageIO, camera.cpp:178-188) stays with the host application.
+ */
+int vmx_quantize_device(const void *d_frame_rgbaz, uint64_t npixels, void *d_rgba8, void *d_depth, int device,
+                        void *stream);
 
 #ifdef __cplusplus
 }

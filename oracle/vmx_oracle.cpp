@@ -163,6 +163,10 @@ struct orc_scene {
     std::vector<FlatNode> nodes;
     std::vector<vmx_sphere> spheres;
     uint32_t leaf_size = 4, n_leaves = 0, max_depth = 0;
+    /* boundTextures[0] (meshEngine.h:62): VermiTexture{nWidth,nHeight,nChannels,pData}, meshEngine.cpp:7-19 */
+    std::vector<float> tex;
+    uint16_t tex_w = 0, tex_h = 0, tex_c = 0;
+    uint32_t n_textures = 0;
 };
 
 namespace {
@@ -497,8 +501,25 @@ inline bool finite1(float f) {
 }
 inline bool finite3(V3 v) { return finite1(v.x) && finite1(v.y) && finite1(v.z); }
 
+/* VermiTexture::Sample, meshEngine.cpp:21-46: wrap by x - floor(x), nearest by round(x*(W-1)) */
+inline void texture_sample(const orc_scene &sc, V2 uv, V4 *out) {
+    float sx = uv.x - std::floor(uv.x);
+    float sy = uv.y - std::floor(uv.y);
+    uint32_t mx = (uint32_t)std::round(sx * (sc.tex_w - 1));
+    uint32_t my = (uint32_t)std::round(sy * (sc.tex_h - 1));
+    const float *ptr = &sc.tex[((size_t)my * sc.tex_w + mx) * sc.tex_c];
+    switch (sc.tex_c) {
+        case 1: *out = V4{ptr[0], ptr[0], ptr[0], ptr[0]}; break;
+        case 2: *out = V4{ptr[0], ptr[1], 0, 0}; break;
+        case 3: *out = V4{ptr[0], ptr[1], ptr[2], 0}; break;
+        case 4: *out = V4{ptr[0], ptr[1], ptr[2], ptr[3]}; break;
+        default:;
+    }
+}
+
 /* Radiance, pathtracer.cpp:21-198.  No texture is bound in any configuration
- * (pathtracer.cpp:63-66 not taken), so sampleColour is (1,1,1,1) (:75-79). */
+ * (pathtracer.cpp:63-66 not taken), so sampleColour is (1,1,1,1) (:75-79) unless a
+ * texture was bound with orc_scene_bind_texture (then :63-66, VermiTexture::Sample). */
 template <class Rng>
 V4 radiance(const orc_scene &sc, V3 rStart, V3 rDir, Rng &rng, uint32_t sampling, PathStats *st,
             bool count_nodes) {
@@ -521,7 +542,11 @@ V4 radiance(const orc_scene &sc, V3 rStart, V3 rDir, Rng &rng, uint32_t sampling
         if (depth == 0) accumColour.w = c.distance;                                            /* :44-47 */
         if (length(c.colour) > 1.f) return accumColour;                                        /* :52 */
         if (++depth > 5 && (rng.u01() > 0.95f || depth > 1000)) return accumColour;            /* :56-59 */
-        V4 sampleColour = {1.f, 1.f, 1.f, 1.0};                                                /* :75-79 */
+        V4 sampleColour = {0.f, 0.f, 0.f, 0.f}; /* :62 */
+        if (c.material && sc.n_textures > 0)
+            texture_sample(sc, c.uv, &sampleColour); /* :63-66 */
+        else
+            sampleColour = V4{1.f, 1.f, 1.f, 1.0}; /* :75-79 */
         V3 n = c.normal;
         V3 next_dir;
         if (c.material && rng.u01() >= 0.96) { /* :98-109 specular */
@@ -734,6 +759,18 @@ orc_scene *orc_scene_create(const float *pos, const float *nrm, const float *uv,
 
 void orc_scene_destroy(orc_scene *sc) { delete sc; }
 
+/* MeshEngine::bindTexture (meshEngine.cpp:74-93) without the OIIO read: only boundTextures[0] is
+ * ever sampled (pathtracer.cpp:65) */
+int orc_scene_bind_texture(orc_scene *sc, const float *data, uint32_t w, uint32_t h, uint32_t c) {
+    if (!sc || !data || w == 0 || h == 0 || c == 0 || c > 4 || w > 65535 || h > 65535) return 1;
+    if (sc->n_textures == 0) {
+        sc->tex.assign(data, data + (size_t)w * h * c);
+        sc->tex_w = (uint16_t)w, sc->tex_h = (uint16_t)h, sc->tex_c = (uint16_t)c;
+    }
+    sc->n_textures++;
+    return 0;
+}
+
 void orc_scene_describe(const orc_scene *sc, uint32_t *n_nodes, uint32_t *n_leaves,
                         uint32_t *max_depth) {
     if (n_nodes) *n_nodes = (uint32_t)sc->nodes.size();
@@ -867,6 +904,17 @@ void orc_stream(uint64_t seed, uint32_t pixel, uint32_t k, uint32_t n, uint64_t 
 }
 
 uint64_t orc_splitmix64(uint64_t *state) { return splitmix64(*state); }
+
+/* Camera::saveFrame conversion loop, camera.cpp:159-163 (RGBAZ) */
+void orc_quantize(const float *frame, uint64_t npix, unsigned char *rgba8, float *depth) {
+    for (uint64_t p = 0; p < npix; ++p) {
+        rgba8[p * 4 + 0] = static_cast<unsigned char>(std::floor(frame[p * 5 + 0] * 255));
+        rgba8[p * 4 + 1] = static_cast<unsigned char>(std::floor(frame[p * 5 + 1] * 255));
+        rgba8[p * 4 + 2] = static_cast<unsigned char>(std::floor(frame[p * 5 + 2] * 255));
+        rgba8[p * 4 + 3] = static_cast<unsigned char>(std::floor(frame[p * 5 + 3] * 255));
+        if (depth) depth[p] = frame[p * 5 + 4];
+    }
+}
 
 int orc_max_threads(void) {
 #ifdef _OPENMP

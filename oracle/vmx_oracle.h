@@ -37,6 +37,7 @@ const vmx_sphere *orc_default_spheres(uint32_t *count);
 orc_scene *orc_scene_create(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                             const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size);
 void orc_scene_destroy(orc_scene *);
+int orc_scene_bind_texture(orc_scene *, const float *data, uint32_t w, uint32_t h, uint32_t channels);
 void orc_scene_describe(const orc_scene *, uint32_t *n_nodes, uint32_t *n_leaves,
                         uint32_t *max_depth);
 void orc_scene_bvh(const orc_scene *, uint32_t *start, uint32_t *nprims, uint32_t *right_offset,
@@ -67,6 +68,8 @@ uint64_t orc_splitmix64(uint64_t *state);
 void orc_render(const orc_scene *, const vmx_camera *cam, const vmx_opts *opts, int rng_mode,
                 int threads, float *out_rgbaz, vmx_stats *stats);
 int orc_max_threads(void);
+/* Camera::saveFrame conversion (camera.cpp:159-163) */
+void orc_quantize(const float *frame, uint64_t npix, unsigned char *rgba8, float *depth);
 
 #ifdef __cplusplus
 }

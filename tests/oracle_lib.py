@@ -44,6 +44,7 @@ def lib(fast=False):
     l.orc_scene_create.restype = P
     l.orc_scene_create.argtypes = [P, P, P, C.c_uint32, P, C.c_uint32, C.c_uint32]
     l.orc_scene_destroy.argtypes = [P]
+    l.orc_scene_bind_texture.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_uint32]
     l.orc_scene_describe.argtypes = [P] + [C.POINTER(C.c_uint32)] * 3
     l.orc_scene_bvh.argtypes = [P] * 6
     l.orc_trace.argtypes = [P, P, P, C.c_uint32, P, P, C.POINTER(TraceCounters)]
@@ -58,6 +59,7 @@ def lib(fast=False):
     l.orc_render.argtypes = [P, C.POINTER(L.CameraDesc), C.POINTER(L.Opts), C.c_int, C.c_int, P,
                              C.POINTER(L.Stats)]
     l.orc_max_threads.restype = C.c_int
+    l.orc_quantize.argtypes = [P, C.c_uint64, P, P]
     _libs[name] = l
     return l
 
@@ -91,6 +93,13 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def bind_texture(self, data):
+        data = np.ascontiguousarray(data, np.float32)
+        h, w = data.shape[0], data.shape[1]
+        c = 1 if data.ndim == 2 else data.shape[2]
+        if self.l.orc_scene_bind_texture(self.h, data.ctypes.data, w, h, c) != 0:
+            raise ValueError("bad texture")
 
     def describe(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -170,3 +179,12 @@ def stream(seed, pixel, k, n):
 
 def max_threads():
     return lib().orc_max_threads()
+
+
+def quantize(frame):
+    frame = np.ascontiguousarray(frame, np.float32).reshape(-1, 5)
+    n = frame.shape[0]
+    rgba = np.empty((n, 4), np.uint8)
+    depth = np.empty(n, np.float32)
+    lib().orc_quantize(frame.ctypes.data, n, rgba.ctypes.data, depth.ctypes.data)
+    return rgba, depth

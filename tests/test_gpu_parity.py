@@ -295,3 +295,100 @@ def test_plugin_surface_end_to_end():
     assert np.array_equal(bits(cam.image()), bits(ref))
     hit, mat, loc, nrm_, dist, uvv, col = mEng.RayCast([[0, 420, 1900]], [[0, 0, -1]])
     assert hit[0] and mat[0] and abs(dist[0] - 2700.0) < 1e-3
+
+
+def test_cpp_host_through_c_abi(tmp_path):
+    """examples/render_cornell.cpp: a C++ host in main.cpp's call order, linking only the C ABI"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "render_cornell")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    out = tmp_path / "c.ppm"
+    r = subprocess.run([exe, str(out), "96", "64", "16", "5"], capture_output=True, text=True, check=True)
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n96 64\n255\n") and len(data) == len(b"P6\n96 64\n255\n") + 96 * 64 * 3
+    pos, nrm, uv = scenes.cornell8()
+    c = scenes.cornell_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 96, 64, 16, back_size=(3.6, 3.6 * 64 / 96))
+    ref, rst = O.OracleScene(pos, nrm, uv).render(cam, va.make_opts(seed=5))
+    want = np.floor(ref[:, :, :3] * np.float32(255.0)).astype(np.uint8).tobytes()
+    assert data[len(b"P6\n96 64\n255\n"):] == want
+    assert f"rays {rst['rays_primary']} " in r.stdout
+
+
+def test_frame_output_quantisation_f3():
+    """§8 f-3: Camera::saveFrame's float -> u8 / depth conversion on the device, byte-exact"""
+    import torch
+    import ctypes as C
+    rng = np.random.RandomState(3)
+    frame = rng.rand(37 * 53, 5).astype(np.float32)
+    frame[:, 3] = 1.0
+    frame[:7, :3] = [[0, 0, 0], [1, 1, 1], [0.5, 0.25, 0.999999], [1 / 255, 2 / 255, 254.9999 / 255],
+                     [0.003921568, 0.003921569, 0.00392157], [0.9960784, 0.9960785, 0.99607], [1e-9, 0.99999994, 0.5]]
+    frame[:, 4] = rng.randint(7, 257, size=frame.shape[0])
+    d = torch.from_numpy(frame).cuda()
+    rgba = torch.empty((frame.shape[0], 4), dtype=torch.uint8, device="cuda")
+    depth = torch.empty(frame.shape[0], dtype=torch.float32, device="cuda")
+    va._lib.check(va._lib.lib().vmx_quantize_device(C.c_void_p(d.data_ptr()), frame.shape[0], C.c_void_p(rgba.data_ptr()),
+                                                    C.c_void_p(depth.data_ptr()), 0, None))
+    r_rgba, r_depth = O.quantize(frame)
+    assert np.array_equal(rgba.cpu().numpy(), r_rgba) and np.array_equal(depth.cpu().numpy(), r_depth)
+    assert r_rgba[1].tolist() == [255, 255, 255, 255] and r_rgba[0].tolist() == [0, 0, 0, 255]
+    # through the mirrored Camera
+    cam = va.Camera(va.cameraSettings(imageResX=53, imageResY=37))
+    cam.mImage[:] = frame.reshape(-1)
+    rgba2, depth2 = cam.saveFrameBuffers()
+    assert np.array_equal(rgba2.reshape(-1, 4), r_rgba) and np.array_equal(depth2.reshape(-1), r_depth)
+
+
+def checker_texture(h, w, c, seed):
+    r = np.random.RandomState(seed)
+    t = r.uniform(0.2, 1.0, size=(h, w, c)).astype(np.float32)
+    t[::2, ::2] *= 0.3
+    return t if c > 1 else t[:, :, 0]
+
+
+@pytest.mark.parametrize("channels,size", [(1, (5, 7)), (3, (64, 32)), (4, (2, 2)), (2, (9, 1))])
+def test_textured_paths_bit_exact_f2(channels, size):
+    """§8 f-2: boundTextures[0] sampled at the BVH hit's uv (wrap + nearest) modulates the throughput"""
+    pos, nrm, uv = scenes.bunny70k()
+    uv = uv * np.float32(3.7) - np.float32(1.2)  # leaves [0,1]: exercises the wrap
+    lights = va.spheres_array([
+        dict(centre=(0, 700, 300), radius=220, colour=(1.5, 1.2, 0.9), emit=True),
+        dict(centre=(0, -5e7, 0), radius=5e7), dict(centre=(0, 5e7 + 1000, 0), radius=5e7),
+        dict(centre=(-5e7 + 2000, 0, 0), radius=5e7, normal_sign=-1), dict(centre=(5e7 - 2000, 0, 0), radius=5e7, normal_sign=-1),
+        dict(centre=(0, 0, -5e7 + 2000), radius=5e7, normal_sign=-1), dict(centre=(0, 0, 5e7 - 2000), radius=5e7)])
+    tex = checker_texture(size[0], size[1], channels, channels)
+    p = Pair(pos, nrm, uv, spheres=lights)
+    p.gpu.bind_texture(tex)
+    p.cpu.bind_texture(tex)
+    p.gpu.bind_texture(np.zeros((3, 3), np.float32))  # a second texture is never sampled (pathtracer.cpp:65)
+    p.cpu.bind_texture(np.zeros((3, 3), np.float32))
+    c = scenes.bunny_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 128, 96, 16, back_size=(3.6, 2.7))
+    for sampling in (0, 1):
+        opts = va.make_opts(seed=31, sampling=sampling)
+        o, d = O.primary_rays(cam, opts, 0)
+        rad, st = p.gpu.radiance(o, d, opts)
+        rrad, rst = p.cpu.radiance(o, d, opts)
+        assert np.array_equal(bits(rad), bits(rrad))
+        for es in (0, 1):
+            for pipeline in (0, 1, 4):
+                o2 = va.make_opts(seed=31, sampling=sampling, early_stop=bool(es), pipeline=pipeline, max_paths=40000)
+                img, _ = p.gpu.render(cam, o2)
+                if pipeline == 0:
+                    ref, _ = p.cpu.render(cam, o2)
+                assert np.array_equal(bits(img), bits(ref)), (sampling, es, pipeline)
+    # the texture matters: the untextured frame differs
+    q = va.Scene(pos, nrm, uv, spheres=lights)
+    plain, _ = q.render(cam, va.make_opts(seed=31, sampling=1))
+    tinted, _ = p.gpu.render(cam, va.make_opts(seed=31, sampling=1))
+    assert not np.array_equal(plain, tinted) and tinted[:, :, :3].mean() > 0.005
+    with pytest.raises(va.VmxError):
+        p.gpu.render(cam, va.make_opts(seed=31, pipeline=2))
+    with pytest.raises(va.VmxError):
+        q.bind_texture(np.zeros((2, 2, 5), np.float32))
+    q.close()
+    p.close()

@@ -237,3 +237,40 @@ def test_mt_radiance_is_deterministic_per_seed(cornell):
     a = cornell.radiance_mt(o, d, seeds)
     assert np.array_equal(bits(a), bits(cornell.radiance_mt(o, d, seeds)))
     assert np.all(a[:, 3] > 0)  # w = primary hit distance (pathtracer.cpp:44-47)
+
+
+# ---- §8 f-2: VermiTexture::Sample (meshEngine.cpp:21-46) -------------------------------------
+def test_texture_sample_known_answers():
+    """wrap by x - floor(x), nearest by round(x*(W-1)); the texel modulates the throughput of the
+    diffuse-with-material branch only (pathtracer.cpp:153)"""
+    pos = np.float32([[-500, 0, -500, 500, 0, -500, 500, 0, 500], [-500, 0, -500, 500, 0, 500, -500, 0, 500]])
+    nrm = np.float32([[0, 1, 0] * 3] * 2)
+    uv = np.float32([[0, 0, 2, 0, 2, 2], [0, 0, 2, 2, 0, 2]])  # uv spans [0,2]^2: wraps once
+    lights = va.spheres_array([dict(centre=(0, 900, 0), radius=300, colour=(2, 2, 2), emit=True)])
+    tex = np.zeros((2, 4, 3), np.float32)
+    tex[0, :, 0] = [0.1, 0.2, 0.3, 0.4]
+    tex[1, :, 0] = [0.5, 0.6, 0.7, 0.8]
+    tex[:, :, 1] = 1.0
+    tex[:, :, 2] = 0.25
+    sc = O.OracleScene(pos, nrm, uv, spheres=lights)
+    sc.bind_texture(tex)
+    # straight down onto the quad; with r2 = U every diffuse bounce continues upwards and most hit the light
+    n = 4000
+    o = np.tile(np.float32([-250, 400, -250]), (n, 1))   # uv = (0.5, 0.5): mx = round(.5*3) = 2, my = round(.5*1) = 1... 
+    d = np.tile(np.float32([0, -1, 0]), (n, 1))
+    rad, _ = sc.radiance(o, d, va.make_opts(seed=1, sampling=va.VMX_SAMPLING_CORRECTED))
+    lit = rad[:, 0] > 0
+    assert lit.mean() > 0.05
+    # k diffuse bounces on the quad before the light: green texel 1 -> 2, blue texel .25 -> 2*.25^k,
+    # red = 2 * product of texels; one-bounce paths sample texel (my = 1, mx = round(.5*3) = 2) = 0.7
+    assert np.allclose(rad[lit, 1], 2.0)
+    k = np.round(np.log(rad[lit, 2] / 2.0) / np.log(0.25)).astype(int)
+    assert k.min() == 1 and np.allclose(rad[lit, 2], 2.0 * 0.25 ** k)
+    one = rad[lit][k == 1]
+    assert len(one) > 50 and np.allclose(one[:, 0], 1.4)  # my = round(0.5 * 1) = 1 (half away from zero): row 1
+    # without a texture the same paths return the untinted light
+    sc2 = O.OracleScene(pos, nrm, uv, spheres=lights)
+    rad2, _ = sc2.radiance(o, d, va.make_opts(seed=1, sampling=va.VMX_SAMPLING_CORRECTED))
+    assert np.array_equal(rad2[:, 0] > 0, lit) and np.allclose(rad2[lit, :3], 2.0)
+    with pytest.raises(ValueError):
+        sc2.bind_texture(np.zeros((2, 2, 5), np.float32))

@@ -135,6 +135,7 @@ SYMBOLS = {
     "vmx_default_spheres": (C.POINTER(Sphere), [C.POINTER(C.c_uint32)]),
     "vmx_scene_create": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
     "vmx_scene_destroy": (C.c_int, [_P]),
+    "vmx_scene_bind_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vmx_scene_describe": (C.c_int, [_P, C.POINTER(SceneDesc)]),
     "vmx_scene_bvh": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "vmx_trace": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
@@ -144,6 +145,7 @@ SYMBOLS = {
     "vmx_local_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "vmx_render": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),
     "vmx_render_device": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, _P, C.POINTER(Stats)]),
+    "vmx_quantize_device": (C.c_int, [_P, C.c_uint64, _P, _P, C.c_int, _P]),
     "vmx_assemble_device": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_int, _P]),
 }
 

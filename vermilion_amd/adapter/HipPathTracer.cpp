@@ -42,6 +42,12 @@ bool HipPathTracer::upload(MeshEngine *mEng) {
         std::fprintf(stderr, "HipPathTracer: %s\n", vmx_last_error());
         return false;
     }
+    // boundTextures[0] is the only texture Radiance samples (pathtracer.cpp:63-66)
+    if (!mEng->boundTextures.empty()) {
+        const VermiTexture &tx = mEng->boundTextures[0];
+        if (vmx_scene_bind_texture(mScene, tx.pData, tx.nWidth, tx.nHeight, tx.nChannels) != VMX_OK)
+            std::fprintf(stderr, "HipPathTracer: %s\n", vmx_last_error());
+    }
     mUploadedFrom = mEng;
     mUploadedFaces = faces;
     return true;

@@ -112,6 +112,23 @@ class Camera:
     def image(self):
         return self.mImage.reshape(self.uImageV, self.uImageU, _CHANNELS[self.renderMode])
 
+    def saveFrameBuffers(self, device=0):
+        """The conversion loop of Camera::saveFrame (camera.cpp:140-175) for RGBAZ, on the device:
+        -> (rgba8 [H,W,4] uint8, depth [H,W] float32).  Encoding to PNG/EXR (OIIO) is the host's."""
+        if self.renderMode != vermRenderMode.RGBAZ:
+            raise Exception("saveFrameBuffers: RGBAZ only")
+        import ctypes as C
+        import torch
+        dev = torch.device("cuda", device)
+        frame = torch.from_numpy(self.mImage).to(dev)
+        n = self.RenderTargetSize
+        rgba = torch.empty((n, 4), dtype=torch.uint8, device=dev)
+        depth = torch.empty((n,), dtype=torch.float32, device=dev)
+        L.check(L.lib().vmx_quantize_device(C.c_void_p(frame.data_ptr()), n, C.c_void_p(rgba.data_ptr()),
+                                            C.c_void_p(depth.data_ptr()), device, None))
+        return (rgba.cpu().numpy().reshape(self.uImageV, self.uImageU, 4),
+                depth.cpu().numpy().reshape(self.uImageV, self.uImageU))
+
     def _desc(self):
         return make_camera(self.mPosition, self.rotationDegrees, self.uImageU, self.uImageV,
                            self.uSamplesPerPixel, self.mDistToFilm, (self.sensorSizeX, self.sensorSizeY))
@@ -125,12 +142,22 @@ class MeshEngine:
     def __init__(self, device=0):
         self.device = device
         self.sceneAccelerator = None  # vermilion_amd.Scene
-        self.boundTextures = []       # texture sampling is §8 f-2 (not on the path at any config)
+        self.boundTextures = []       # float images; only [0] is sampled (pathtracer.cpp:65)
 
     def loadTriangles(self, pos, nrm, uv=None, spheres=None, leaf_size=4):
         if self.sceneAccelerator is not None:
             self.sceneAccelerator.close()  # meshEngine.cpp:722
         self.sceneAccelerator = Scene(pos, nrm, uv, spheres=spheres, leaf_size=leaf_size, device=self.device)
+        return True
+
+    def bindTexture(self, image):
+        """MeshEngine::bindTexture (meshEngine.cpp:74-93) with the decoded float image in place of
+        the file name (the OpenImageIO read stays with the host).  Returns False like the reference
+        when nothing usable was given."""
+        if image is None or self.sceneAccelerator is None:
+            return False
+        self.sceneAccelerator.bind_texture(image)
+        self.boundTextures.append(np.asarray(image, np.float32))
         return True
 
     def RayCast(self, rayStart, rayDirection):

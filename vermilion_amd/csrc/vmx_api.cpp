@@ -107,7 +107,7 @@ struct Workspace {
     DevBuf<unsigned int> queue_counts;  // 2 * kSubQueues * 32
     DevBuf<unsigned int> heads;         // kSubQueues * 32 reservation heads of k_paths
     DevBuf<unsigned char> overflow_stack;  // k_paths: stack levels beyond the LDS part
-    DevBuf<unsigned char> rayA, rayB, rngA, rngB, hit;  // split wavefront: per-path state
+    DevBuf<unsigned char> rayA, rayB, rngA, rngB, hit, thr;  // split wavefront: per-path state
     DevBuf<unsigned int> ids[2], id_counts;             // split wavefront: live path ids
     DevBuf<unsigned char> rad;          // float4 per path of a pass
     DevBuf<unsigned char> accum;        // float4 per local pixel
@@ -119,7 +119,7 @@ struct Workspace {
     EventPool events;
     void release() {
         queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), heads.release(), overflow_stack.release();
-        rayA.release(), rayB.release(), rngA.release(), rngB.release(), hit.release();
+        rayA.release(), rayB.release(), rngA.release(), rngB.release(), hit.release(), thr.release();
         ids[0].release(), ids[1].release(), id_counts.release();
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
@@ -138,6 +138,8 @@ struct vmx_scene {
     DevBuf<TriRecord> d_tris;
     DevBuf<AttrRecord> d_attrs;
     DevBuf<SphereDev> d_spheres;
+    DevBuf<float> d_tex;
+    uint32_t n_textures = 0;
     SceneDev dev{};
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -354,6 +356,11 @@ int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[2]) {
         return fail(VMX_ERR_NOMEM, "hipMalloc failed for the path arrays");
     pa.rayA = ws.rayA.p, pa.rayB = ws.rayB.p, pa.rngA = ws.rngA.p, pa.rngB = ws.rngB.p;
     pa.hit = ws.hit.p, pa.rad = ws.rad.p;
+    pa.thr = nullptr;
+    if (sc->dev.tex) {
+        if (ws.thr.ensure(nslots * 16)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the throughput plane");
+        pa.thr = ws.thr.p;
+    }
     for (int i = 0; i < 2; ++i) {
         q[i].ids = ws.ids[i].p;
         q[i].counts = ws.id_counts.p + (size_t)i * kSubQueues * 32;
@@ -483,6 +490,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     //     kernel, which needs no per-generation host round trip)
     const uint32_t pipeline = opts->reserved[0];
     if (pipeline > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    if (sc->dev.tex && pipeline >= 2 && pipeline <= 3)
+        return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
     const bool split_any = pipeline == 0 || pipeline == 4;
     const bool legacy = pipeline >= 2 && pipeline <= 3;
     const uint64_t kHybridPaths = std::getenv("VMX_HYBRID") ? std::strtoull(std::getenv("VMX_HYBRID"), nullptr, 10) : (4ull << 20);
@@ -775,8 +784,27 @@ int vmx_scene_destroy(vmx_scene *sc) {
     (void)hipSetDevice(sc->device);
     sc->ws.release();
     sc->d_inner.release(), sc->d_tris.release(), sc->d_attrs.release(), sc->d_spheres.release();
+    sc->d_tex.release();
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
+    return VMX_OK;
+}
+
+int vmx_scene_bind_texture(vmx_scene *sc, const float *data, uint32_t width, uint32_t height, uint32_t channels) {
+    if (!sc || !data) return fail(VMX_ERR_INVALID, "NULL argument");
+    if (width == 0 || height == 0 || channels == 0 || channels > 4 || width > 65535 || height > 65535)
+        return fail(VMX_ERR_INVALID, "texture must be 1..65535 texels wide/high with 1..4 channels");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    int rc = bind_device(sc);
+    if (rc) return rc;
+    if (sc->n_textures == 0) {  // only boundTextures[0] is sampled (pathtracer.cpp:65)
+        const size_t n = (size_t)width * height * channels;
+        if (sc->d_tex.ensure(n)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the texture");
+        HIP_TRY(hipMemcpy(sc->d_tex.p, data, n * 4, hipMemcpyHostToDevice));
+        sc->dev.tex = sc->d_tex.p;
+        sc->dev.tex_w = width, sc->dev.tex_h = height, sc->dev.tex_c = channels;
+    }
+    sc->n_textures++;
     return VMX_OK;
 }
 
@@ -895,7 +923,9 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     vmx_scene *sc = const_cast<vmx_scene *>(csc);
     if (!sc || !origin || !dir || !opts || !out) return fail(VMX_ERR_INVALID, "NULL argument");
     if (opts->sampling > VMX_SAMPLING_CORRECTED) return fail(VMX_ERR_INVALID, "unknown sampling mode");
-    if (opts->reserved[0] > 3) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    if (opts->reserved[0] > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    if (sc->dev.tex && opts->reserved[0] >= 2 && opts->reserved[0] <= 3)
+        return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
     if (n == 0) return VMX_OK;
     const auto t0 = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> lock(sc->mu);
@@ -904,7 +934,7 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     Workspace &ws = sc->ws;
     hipStream_t s = sc->stream;
     const bool count = opts->collect_counters != 0;
-    const bool legacy = opts->reserved[0] >= 2;  // first-generation kernels (96-byte path records)
+    const bool legacy = opts->reserved[0] == 2 || opts->reserved[0] == 3;  // first-generation kernels
     const Tuning tn = make_tuning(sc, opts);
     FrameDev fr;
     std::memset(&fr, 0, sizeof(fr));
@@ -1006,6 +1036,19 @@ int vmx_assemble_device(const void *d_gathered, uint64_t rank_stride_floats, uin
     HIP_TRY(hipSetDevice(device));
     LAUNCH_TRY(launch_assemble((const float *)d_gathered, rank_stride_floats, width, height,
                                stripe_rows ? stripe_rows : 16u, world, (float *)d_frame, stream));
+    if (!stream) HIP_TRY(hipDeviceSynchronize());
+    return VMX_OK;
+}
+
+int vmx_quantize_device(const void *d_frame_rgbaz, uint64_t npixels, void *d_rgba8, void *d_depth, int device,
+                        void *stream) {
+    if (!d_frame_rgbaz || !d_rgba8) return fail(VMX_ERR_INVALID, "NULL argument");
+    if (npixels == 0) return VMX_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(VMX_ERR_NO_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    LAUNCH_TRY(launch_quantize((const float *)d_frame_rgbaz, npixels, d_rgba8, (float *)d_depth, stream));
     if (!stream) HIP_TRY(hipDeviceSynchronize());
     return VMX_OK;
 }

@@ -70,6 +70,9 @@ struct SceneDev {
     uint32_t nspheres;
     uint32_t stack_entries;  // per-lane LDS stack entries (max tree depth + 2)
     uint32_t ntris;
+    // boundTextures[0] (meshEngine.h:62): float[h][w][c] as bindTexture reads it (meshEngine.cpp:74-93)
+    const float *tex;
+    uint32_t tex_w, tex_h, tex_c, tex_pad;
 };
 
 // per-stage device counters (one set for depth-0 steps, one for bounce steps)

@@ -30,6 +30,7 @@ struct PathArrays {
     void *rngB;   // float4 = xoshiro s2, s3
     void *hit;    // float2 (t of the BVH query, bits(leaf slot or -1))
     void *rad;    // float4 accumColour, updated in place; final when the path ends
+    void *thr;    // float4 accumRadiance (rgb); only with a bound texture (else it stays 1,1,1)
 };
 
 // compacted list of live path ids: kSubQueues sub-lists, each `sub_capacity` ids long
@@ -111,6 +112,7 @@ int launch_radiance_init_ids(const float *o, const float *d, uint32_t n, uint64_
 int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,
                    const void *rad, PixelStateDev px, unsigned int *next_active,
                    unsigned int *next_count, float *out_rgbaz, DevCounters *counters, void *stream);
+int launch_quantize(const float *frame, uint64_t npix, void *rgba8, float *depth, void *stream);
 int launch_assemble(const float *gathered, uint64_t rank_stride_floats, uint32_t width, uint32_t height,
                     uint32_t stripe_rows, uint32_t world, float *frame, void *stream);
 

@@ -386,6 +386,7 @@ __device__ __forceinline__ void ray_cast(const SceneDev &sc, float ox, float oy,
 // ---------------------------------------------------------------------------
 struct Path {
     float ox, oy, oz, dx, dy, dz;
+    float tr, tg, tb;      // accumRadiance (rgb); only maintained by the textured kernels
     float ar, ag, ab, aw;  // accumColour
     uint32_t depth, dest;
     Rng rng;
@@ -397,15 +398,40 @@ struct StepFlags {
 
 // Radiance's loop body after RayCast (pathtracer.cpp:36-196).
 // returns true if the path continues with a new ray in P, false if accumColour is final
-__device__ __forceinline__ bool path_shade(float r2scale, Path &P, const CastResult &c, StepFlags &fl) {
+// VermiTexture::Sample (meshEngine.cpp:21-46): wrap x - floor(x), nearest round(x*(W-1)), 1-4 channels.
+// The texel index is clamped (the reference indexes out of bounds on a NaN uv).
+__device__ __forceinline__ float4 tex_sample(const SceneDev &sc, float u, float v) {
+    const float sx = u - floorf(u), sy = v - floorf(v);
+    uint32_t mx = (uint32_t)roundf(sx * (float)(int)(sc.tex_w - 1));
+    uint32_t my = (uint32_t)roundf(sy * (float)(int)(sc.tex_h - 1));
+    mx = min(mx, sc.tex_w - 1);
+    my = min(my, sc.tex_h - 1);
+    const float *p = sc.tex + ((size_t)my * sc.tex_w + mx) * sc.tex_c;
+    switch (sc.tex_c) {
+        case 1: return make_float4(p[0], p[0], p[0], p[0]);
+        case 2: return make_float4(p[0], p[1], 0.f, 0.f);
+        case 3: return make_float4(p[0], p[1], p[2], 0.f);
+        default: return make_float4(p[0], p[1], p[2], p[3]);
+    }
+}
+
+template <bool TEX>
+__device__ __forceinline__ bool path_shade(const SceneDev &sc, float r2scale, Path &P, const CastResult &c,
+                                           StepFlags &fl) {
     fl.tri_hit = c.slot >= 0;
     fl.continues = false;
     if (!(c.nearest < kInf)) return false;  // pathtracer.cpp:36-41
-    // :43 — accumRadiance stays (1,1,1,1): the only factor ever applied to it is the white
-    // albedo of the untextured path (:75-79,153), so the product is exactly hitColour
-    P.ar = P.ar + c.cr;
-    P.ag = P.ag + c.cg;
-    P.ab = P.ab + c.cb;
+    if (TEX) {  // :43
+        P.ar = P.ar + P.tr * c.cr;
+        P.ag = P.ag + P.tg * c.cg;
+        P.ab = P.ab + P.tb * c.cb;
+    } else {
+        // untextured: accumRadiance stays (1,1,1,1) — the only factor ever applied to it is the white
+        // albedo (:75-79,153) — so the product is exactly hitColour
+        P.ar = P.ar + c.cr;
+        P.ag = P.ag + c.cg;
+        P.ab = P.ab + c.cb;
+    }
     if (P.depth == 0) P.aw = c.nearest;                                   // :44-47
     if (sqrtf(dot3(c.cr, c.cg, c.cb, c.cr, c.cg, c.cb)) > 1.f) return false;  // :52
     P.depth++;
@@ -430,7 +456,13 @@ __device__ __forceinline__ bool path_shade(float r2scale, Path &P, const CastRes
         normalize3(ndx, ndy, ndz);
     } else {
         float r2s, cs, sn, q;
-        if (c.material) {  // :151-165 (throughput *= white albedo: exact no-op)
+        if (c.material) {  // :151-165
+            if (TEX) {  // accumRadiance *= sampleColour (:153), sampled at the BVH hit's uv (:63-66)
+                const float4 tx = tex_sample(sc, c.uvx, c.uvy);
+                P.tr = P.tr * tx.x;
+                P.tg = P.tg * tx.y;
+                P.tb = P.tb * tx.z;
+            }
             const float r1 = (float)(6.283185307179586 * rng_u01(P.rng));
             const float r2 = (float)((double)r2scale * rng_u01(P.rng));
             r2s = sqrtf(r2);
@@ -480,7 +512,7 @@ __device__ __forceinline__ bool path_step(const SceneDev &sc, float r2scale, Pat
                                           StepFlags &fl, Cnt &cnt) {
     CastResult c;
     ray_cast<COUNT>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, stk, c, cnt);
-    return path_shade(r2scale, P, c, fl);
+    return path_shade<false>(sc, r2scale, P, c, fl);
 }
 
 // ---------------------------------------------------------------------------
@@ -651,11 +683,16 @@ __device__ __forceinline__ void ray_load(const PathArrays &pa, uint32_t pid, Pat
     P.ox = a.x, P.oy = a.y, P.oz = a.z, P.dx = a.w;
     P.dy = b.x, P.dz = b.y, P.depth = __float_as_uint(b.z);
 }
+template <bool TEX>
 __device__ __forceinline__ void path_load_arrays(const PathArrays &pa, uint32_t pid, Path &P) {
     ray_load(pa, pid, P);
     rng_load(pa, pid, P.rng);
     const float4 acc = ((const float4 *)pa.rad)[pid];
     P.ar = acc.x, P.ag = acc.y, P.ab = acc.z, P.aw = acc.w;
+    if (TEX) {
+        const float4 th = ((const float4 *)pa.thr)[pid];
+        P.tr = th.x, P.tg = th.y, P.tb = th.z;
+    }
     P.dest = pid;
 }
 // id compaction: wave ballot + prefix popcount, one atomic per wave
@@ -936,7 +973,7 @@ __device__ __forceinline__ uint2 stack_pop(const uint2 *stk, const uint2 *ovf, i
     return e;
 }
 
-template <bool COUNT, int SRC, bool LOOP>
+template <bool COUNT, int SRC, bool LOOP, bool TEX>
 __global__ void __launch_bounds__(256)
 k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, float4 *__restrict__ rad,
         PathArrays pa, DevCounters *ctr) {
@@ -993,7 +1030,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                     CastResult c;
                     cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, best, slot, c);
                     fl.was_ray = is_ray;
-                    alive = path_shade(fr.r2scale, P, c, fl);
+                    alive = path_shade<TEX>(sc, fr.r2scale, P, c, fl);
                     if (!alive) {
                         rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
                         has = false;
@@ -1054,6 +1091,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                                     P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz;
                                                         P.ar = P.ag = P.ab = 0.f;
                                     P.aw = -100.f;  // pathtracer.cpp:29
+                                    P.tr = P.tg = P.tb = 1.f;  // :30
                                     P.depth = 0;
                                     P.dest = j * wk.n_pad + s_idx;
                                 }
@@ -1062,7 +1100,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                             path_load(wk.qin, src * wk.qin.sub_capacity + item, P);
                             valid = P.depth != 0xFFFFFFFFu;  // dead slot left by an overflowing append
                         } else {
-                            path_load_arrays(pa, wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item], P);
+                            path_load_arrays<TEX>(pa, wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item], P);
                         }
                         if (valid) {
                             has = true;
@@ -1418,7 +1456,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 //          from (pixel, sample) instead of being stored by the trace kernel
 //   SRC 1: queued path ids; ray, RNG and accumulated colour come from the arrays
 // ---------------------------------------------------------------------------
-template <int SRC>
+template <int SRC, bool TEX>
 __global__ void __launch_bounds__(256)
 k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, IdQueue qout, uint32_t max_chunks,
         DevCounters *ctr) {
@@ -1443,6 +1481,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
                 (void)rng_next(P.rng);
                 P.ar = P.ag = P.ab = 0.f;
                 P.aw = -100.f;  // pathtracer.cpp:29
+                P.tr = P.tg = P.tb = 1.f;  // :30
             }
         } else {
             const uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
@@ -1450,7 +1489,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             run = pos < min(wk.qids.counts[sub * 32], wk.qids.sub_capacity);
             if (run) {
                 pid = wk.qids.ids[(size_t)sub * wk.qids.sub_capacity + pos];
-                path_load_arrays(pa, pid, P);
+                path_load_arrays<TEX>(pa, pid, P);
             }
         }
         StepFlags fl = {false, false, false};
@@ -1463,11 +1502,12 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             const float2 h = hits[pid];
             CastResult c;
             cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c);
-            alive = path_shade(fr.r2scale, P, c, fl);
+            alive = path_shade<TEX>(sc, fr.r2scale, P, c, fl);
             rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
             if (alive) {
                 ray_store(pa, pid, P);
                 rng_store(pa, pid, P.rng);
+                if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, 1.f);
             }
         }
         tally_add(tl, fl, run, depth0);
@@ -1494,6 +1534,7 @@ __global__ void k_radiance_init_ids(const float *__restrict__ o, const float *__
             ray_store(pa, i, P);
             rng_store(pa, i, P.rng);
             ((float4 *)pa.rad)[i] = make_float4(0.f, 0.f, 0.f, -100.f);
+            if (pa.thr) ((float4 *)pa.thr)[i] = make_float4(1.f, 1.f, 1.f, 1.f);
         }
         id_append(qout, (base / blockDim.x) % kSubQueues, run, i);
     }
@@ -1585,6 +1626,21 @@ __global__ void k_assemble(const float *__restrict__ gathered, uint64_t rank_str
         const uint32_t rank = gs % world, ls = gs / world;
         const uint64_t lrow = (uint64_t)ls * stripe_rows + r;
         frame[i] = gathered[rank * rank_stride + lrow * width * 5 + in_row];
+    }
+}
+
+// Camera::saveFrame's conversion loop (camera.cpp:159-163): floor(x*255) -> u8, depth plane
+__global__ void k_quantize(const float *__restrict__ frame, uint64_t npix, uchar4 *__restrict__ rgba8,
+                           float *__restrict__ depth) {
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (uint64_t)gridDim.x * blockDim.x) {
+        const float *f = frame + p * 5;
+        uchar4 o;
+        o.x = (unsigned char)floorf(f[0] * 255.0f);
+        o.y = (unsigned char)floorf(f[1] * 255.0f);
+        o.z = (unsigned char)floorf(f[2] * 255.0f);
+        o.w = (unsigned char)floorf(f[3] * 255.0f);
+        rgba8[p] = o;
+        if (depth) depth[p] = f[4];
     }
 }
 
@@ -1681,14 +1737,19 @@ int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pixe
                  void *stream) {
     hipStream_t s = (hipStream_t)stream;
     dim3 g(cfg.grid), b(cfg.block);
-#define VMX_GO(C, S, L)                                                                                   \
-    hipLaunchKernelGGL((k_paths<C, S, L>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)rad, pa, counters)
+#define VMX_GO(C, S, L, T)                                                                                   \
+    hipLaunchKernelGGL((k_paths<C, S, L, T>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)rad, pa, counters)
     // instantiated forms: primary source following every path to its end (pipeline 1)
     PathArrays pa{};
     (void)from_queue;
     (void)loop_to_end;
-    if (count) VMX_GO(true, 0, true);
-    else VMX_GO(false, 0, true);
+    if (sc.tex) {
+        if (count) VMX_GO(true, 0, true, true);
+        else VMX_GO(false, 0, true, true);
+    } else {
+        if (count) VMX_GO(true, 0, true, false);
+        else VMX_GO(false, 0, true, false);
+    }
 #undef VMX_GO
     return launch_status();
 }
@@ -1699,12 +1760,16 @@ int launch_tail(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathA
     dim3 g(cfg.grid), b(cfg.block);
     PixelStateDev px{nullptr, nullptr, nullptr};
     QueueDev qout{};
-    if (count)
-        hipLaunchKernelGGL((k_paths<true, 2, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)pa.rad, pa,
-                           counters);
-    else
-        hipLaunchKernelGGL((k_paths<false, 2, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)pa.rad,
-                           pa, counters);
+#define VMX_GO(C, T) \
+    hipLaunchKernelGGL((k_paths<C, 2, true, T>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)pa.rad, pa, counters)
+    if (sc.tex) {
+        if (count) VMX_GO(true, true);
+        else VMX_GO(false, true);
+    } else {
+        if (count) VMX_GO(true, false);
+        else VMX_GO(false, false);
+    }
+#undef VMX_GO
     return launch_status();
 }
 
@@ -1753,10 +1818,16 @@ int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pixe
                                       : ((uint64_t)wk.samples * wk.n_pad + 255) / 256;
     uint32_t grid = (uint32_t)std::min<uint64_t>(items, 256u * 16u);
     if (grid == 0) grid = 1;
-    if (from_queue)
-        hipLaunchKernelGGL((k_shade<1>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters);
-    else
-        hipLaunchKernelGGL((k_shade<0>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters);
+#define VMX_GO(S, T) \
+    hipLaunchKernelGGL((k_shade<S, T>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters)
+    if (sc.tex) {
+        if (from_queue) VMX_GO(1, true);
+        else VMX_GO(0, true);
+    } else {
+        if (from_queue) VMX_GO(1, false);
+        else VMX_GO(0, false);
+    }
+#undef VMX_GO
     return launch_status();
 }
 
@@ -1772,11 +1843,11 @@ int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, in
     int a = 0, b = 0;
     hipError_t e;
     if (count) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<true, 0, true>, (int)block, lds_bytes);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<true, 2, true>, (int)block, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<true, 0, true, true>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<true, 2, true, true>, (int)block, lds_bytes);
     } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<false, 0, true>, (int)block, lds_bytes);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<false, 2, true>, (int)block, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<false, 0, true, true>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<false, 2, true, true>, (int)block, lds_bytes);
     }
     if (blocks) *blocks = a < b ? a : b;
     return (int)e;
@@ -1796,6 +1867,13 @@ int launch_assemble(const float *gathered, uint64_t rank_stride_floats, uint32_t
                     uint32_t stripe_rows, uint32_t world, float *frame, void *stream) {
     hipLaunchKernelGGL(k_assemble, dim3(2048), dim3(256), 0, (hipStream_t)stream, gathered, rank_stride_floats, width,
                        height, stripe_rows, world, frame);
+    return launch_status();
+}
+
+int launch_quantize(const float *frame, uint64_t npix, void *rgba8, float *depth, void *stream) {
+    uint32_t grid = (uint32_t)std::min<uint64_t>((npix + 255) / 256, 8192);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_quantize, dim3(grid), dim3(256), 0, (hipStream_t)stream, frame, npix, (uchar4 *)rgba8, depth);
     return launch_status();
 }
 

@@ -109,6 +109,16 @@ class Scene:
     def __exit__(self, *a):
         self.close()
 
+    def bind_texture(self, data):
+        """MeshEngine::bindTexture (meshEngine.cpp:74-93): float image [H, W] or [H, W, C], C <= 4.
+        Only the first bound texture is sampled (pathtracer.cpp:65)."""
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        if data.ndim not in (2, 3):
+            raise ValueError("texture must be [H, W] or [H, W, C]")
+        c = 1 if data.ndim == 2 else data.shape[2]
+        L.check(L.lib().vmx_scene_bind_texture(self._h, data.ctypes.data, data.shape[1], data.shape[0], c))
+        return True
+
     # -- introspection ----------------------------------------------------
     def describe(self):
         d = L.SceneDesc()
