@@ -274,3 +274,23 @@ def test_texture_sample_known_answers():
     assert np.array_equal(rad2[:, 0] > 0, lit) and np.allclose(rad2[lit, :3], 2.0)
     with pytest.raises(ValueError):
         sc2.bind_texture(np.zeros((2, 2, 5), np.float32))
+
+
+def test_bvh_statistics_match_the_survey_probe():
+    """SURVEY App. C ran the reference's BVH::build on sine heightfields: 8 tris -> 3 nodes / 2 leaves;
+    69,938 tris -> 47,871 nodes / 23,936 leaves (0.6845 nodes per triangle); 260,100 -> 130,785 / 65,393
+    (0.5028).  The survey's exact generator is not recorded, so only the 8-triangle case can be matched
+    exactly; the large grids must land within 0.5 % of the recorded node density."""
+    sc = O.OracleScene(*scenes.heightfield(2))
+    assert sc.describe()["n_nodes"] == 3 and sc.describe()["n_leaves"] == 2
+    d = O.OracleScene(*scenes.heightfield(187)).describe()
+    assert abs(d["n_nodes"] / 69938 - 47871 / 69938) < 0.005 and abs(d["n_leaves"] / 69938 - 23936 / 69938) < 0.003
+    assert d["n_nodes"] == 2 * d["n_leaves"] - 1
+    # traversal statistics of downward rays from one origin: ~14 inner visits, ~4-5 triangle tests per ray
+    r = np.random.RandomState(0)
+    dd = np.stack([r.uniform(-.5, .5, 20000), -np.ones(20000), r.uniform(-.5, .5, 20000)], 1)
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    oo = np.tile(np.float32([0, 900, 0]), (20000, 1))
+    tri, t, c = O.OracleScene(*scenes.heightfield(187)).trace(oo, dd.astype(np.float32), counters=True)
+    assert (tri >= 0).mean() > 0.99
+    assert 10 < c["inner_visits"] / 20000 < 22 and 3 < c["tri_tests"] / 20000 < 7 and c["max_stack"] <= 12
