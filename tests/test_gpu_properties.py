@@ -111,3 +111,21 @@ def test_early_stop_never_takes_more_samples_and_keeps_lit_pixels_lit(sponza):
     assert sb["samples"] < sa["samples"] == 480 * 270 * 64
     assert np.all(b[:, :, 4] <= 64) and np.all(b[:, :, 4] >= 9)  # n > sqrt(64) before any stop
     assert b[:, :, :3].mean() > 0.01 and a[:, :, :3].mean() > 0.01
+
+
+def test_4k_frame_config5_geometry(sponza):
+    """BASELINE config 5 image size (3840x2160) on one GPU at low spp: sharding and pipeline forms agree"""
+    cam = sponza_cam(3840, 2160, 8)
+    full, sf = sponza.render(cam, va.make_opts(seed=4, early_stop=False))
+    assert full.shape == (2160, 3840, 5) and sf["samples"] == 3840 * 2160 * 8
+    assert np.all(full[:, :, 4] == 8.0) and np.all(np.isfinite(full))
+    # rank 5 of 8 renders exactly its stripes of the same frame
+    part, sp = sponza.render(cam, va.make_opts(seed=4, early_stop=False, rank=5, world=8, stripe_rows=16))
+    rows = va.local_row_indices(2160, 16, 5, 8)
+    assert np.array_equal(bits(part), bits(full[rows]))
+    # primary-hit map of the full-size frame: exact vs the oracle on a sparse subset
+    tri, t = sponza.primary_ids(cam, va.make_opts(seed=4), 3)
+    o, d = O.primary_rays(cam, va.make_opts(seed=4), 3)
+    sel = np.arange(0, 3840 * 2160, 1013)
+    rtri, rt = O.OracleScene(*scenes.sponza260k()).trace(o[sel], d[sel])
+    assert np.array_equal(tri[sel], rtri) and np.array_equal(bits(t[sel]), bits(rt))
