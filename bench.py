@@ -135,6 +135,31 @@ def main():
     es_k = max(1, min(args.steps, 3))
     es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
 
+    # §8 f-1 quality builder (binned SAH, not the reference's topology): same frame, extra figure only
+    q_info = None
+    if world == 1:
+        qsc = va.Scene(pos, nrm, uv, device=dev_index, builder=va._lib.VMX_BVH_SAH)
+        qopts = va.make_opts(seed=args.seed, early_stop=False, collect_counters=True)
+        qc = qsc.render_device(cam, qopts, local.data_ptr(), stream)
+        qopts = va.make_opts(seed=args.seed, early_stop=False)
+        qsc.render_device(cam, qopts, local.data_ptr(), stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        qk = max(1, min(args.steps, 3))
+        qst = [qsc.render_device(cam, qopts, local.data_ptr(), stream) for _ in range(qk)]
+        torch.cuda.synchronize(dev)
+        qdt = time.perf_counter() - t0
+        qrays = sum(s["rays_primary"] + s["rays_secondary"] for s in qst)
+        q_info = {
+            "what": "same frame over the binned-SAH tree (vmx_scene_create_ex, VMX_BVH_SAH): ties / pruning order "
+                    "follow that tree, so triangle IDs can differ from the reference on exact-distance ties",
+            "Mrays_per_s": round(qrays / qdt / 1e6, 2),
+            "ms_per_frame": round(qdt / qk * 1e3, 3),
+            "inner_visits_per_ray": round(qc["primary"]["inner_visits"] / max(qc["primary"]["rays"], 1), 2),
+            "bvh": {k: qsc.describe()[k] for k in ("n_nodes", "max_depth")},
+        }
+        qsc.close()
+
     if rank == 0:
         prim_ms = sum(s["primary"]["ms"] for s in stats)
         prim_launches = sum(s["primary"]["launches"] for s in stats)
@@ -201,6 +226,8 @@ def main():
                 "passes": es_stats[0]["passes"],
             },
         }
+        if q_info:
+            out["quality_bvh"] = q_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, nrm, uv, c, W, H, args.cpu_spp, args.seed)
         print(json.dumps(out), flush=True)

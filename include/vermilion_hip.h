@@ -172,6 +172,13 @@ const vmx_sphere *vmx_default_spheres(uint32_t *count);
 int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                      const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size,
                      int device, vmx_scene **out);
+/* BVH builders for vmx_scene_create_ex */
+#define VMX_BVH_REFERENCE 0u /* BVH::build's topology (bvh.cpp:179-279): triangle-ID / tie parity        */
+#define VMX_BVH_SAH 1u       /* binned-SAH quality tree: same triangle tests and nearest
+                                distance, but exact-distance ties and `near > t` pruning follow ITS order */
+int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
+                        const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size, uint32_t builder,
+                        int device, vmx_scene **out);
 int vmx_scene_destroy(vmx_scene *scene);
 /*
  * Replaces MeshEngine::bindTexture (meshEngine.cpp:74-93) minus the OpenImageIO read: `data` is the

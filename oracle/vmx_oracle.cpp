@@ -757,6 +757,27 @@ orc_scene *orc_scene_create(const float *pos, const float *nrm, const float *uv,
     return sc;
 }
 
+/* A scene whose flat tree is given (reference layout, bvh.h:11-14) instead of built: lets the tests
+ * run the reference's *traversal* over another builder's tree (SURVEY §8 f-1 quality builder). */
+orc_scene *orc_scene_create_from_tree(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
+                                      const vmx_sphere *spheres, uint32_t nspheres, uint32_t n_nodes,
+                                      const uint32_t *start, const uint32_t *nprims, const uint32_t *right_offset,
+                                      const float *bbox, const uint32_t *prim_order) {
+    orc_scene *sc = orc_scene_create(pos, nrm, uv, ntris, spheres, nspheres, 4);
+    if (!sc) return nullptr;
+    sc->nodes.assign(n_nodes, FlatNode{});
+    sc->n_leaves = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        FlatNode &n = sc->nodes[i];
+        n.start = start[i], n.nprims = nprims[i], n.right_offset = right_offset[i];
+        const float *b = bbox + (size_t)i * 6;
+        n.box = box_of(v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5]));
+        if (n.right_offset == 0) sc->n_leaves++;
+    }
+    for (uint32_t i = 0; i < ntris; ++i) sc->prims[i] = &sc->tris[prim_order[i]];
+    return sc;
+}
+
 void orc_scene_destroy(orc_scene *sc) { delete sc; }
 
 /* MeshEngine::bindTexture (meshEngine.cpp:74-93) without the OIIO read: only boundTextures[0] is

@@ -36,6 +36,10 @@ const vmx_sphere *orc_default_spheres(uint32_t *count);
 
 orc_scene *orc_scene_create(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                             const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size);
+orc_scene *orc_scene_create_from_tree(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
+                                      const vmx_sphere *spheres, uint32_t nspheres, uint32_t n_nodes,
+                                      const uint32_t *start, const uint32_t *nprims, const uint32_t *right_offset,
+                                      const float *bbox, const uint32_t *prim_order);
 void orc_scene_destroy(orc_scene *);
 int orc_scene_bind_texture(orc_scene *, const float *data, uint32_t w, uint32_t h, uint32_t channels);
 void orc_scene_describe(const orc_scene *, uint32_t *n_nodes, uint32_t *n_leaves,

@@ -44,6 +44,8 @@ def lib(fast=False):
     l.orc_scene_create.restype = P
     l.orc_scene_create.argtypes = [P, P, P, C.c_uint32, P, C.c_uint32, C.c_uint32]
     l.orc_scene_destroy.argtypes = [P]
+    l.orc_scene_create_from_tree.restype = P
+    l.orc_scene_create_from_tree.argtypes = [P, P, P, C.c_uint32, P, C.c_uint32, C.c_uint32, P, P, P, P, P]
     l.orc_scene_bind_texture.argtypes = [P, P, C.c_uint32, C.c_uint32, C.c_uint32]
     l.orc_scene_describe.argtypes = [P] + [C.POINTER(C.c_uint32)] * 3
     l.orc_scene_bvh.argtypes = [P] * 6
@@ -69,7 +71,8 @@ def _f32(a):
 
 
 class OracleScene:
-    def __init__(self, pos, nrm, uv=None, spheres=None, leaf_size=4, fast=False):
+    def __init__(self, pos, nrm, uv=None, spheres=None, leaf_size=4, fast=False, tree=None):
+        """tree: dict as returned by Scene.bvh() — traverse that flat tree instead of building one"""
         self.l = lib(fast)
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 9)
         nrm = np.ascontiguousarray(nrm, np.float32).reshape(-1, 9)
@@ -79,7 +82,14 @@ class OracleScene:
             uvp = uv.ctypes.data
         sp, nsp = (None, 0) if spheres is None else (C.addressof(spheres), len(spheres))
         self.ntris = pos.shape[0]
-        self.h = self.l.orc_scene_create(pos.ctypes.data, nrm.ctypes.data, uvp, self.ntris, sp, nsp, leaf_size)
+        if tree is not None:
+            t = {k: np.ascontiguousarray(v) for k, v in tree.items()}
+            self.h = self.l.orc_scene_create_from_tree(pos.ctypes.data, nrm.ctypes.data, uvp, self.ntris, sp, nsp,
+                                                       len(t["start"]), t["start"].ctypes.data, t["nprims"].ctypes.data,
+                                                       t["right_offset"].ctypes.data, t["bbox"].ctypes.data,
+                                                       t["prim_order"].ctypes.data)
+        else:
+            self.h = self.l.orc_scene_create(pos.ctypes.data, nrm.ctypes.data, uvp, self.ntris, sp, nsp, leaf_size)
         if not self.h:
             raise RuntimeError("orc_scene_create failed")
 

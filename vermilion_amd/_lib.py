@@ -20,6 +20,8 @@ VMX_ERR_NOMEM = 5
 VMX_SPHERE_EMIT = 1
 VMX_SAMPLING_PARITY = 0
 VMX_SAMPLING_CORRECTED = 1
+VMX_BVH_REFERENCE = 0
+VMX_BVH_SAH = 1
 
 
 class Sphere(C.Structure):
@@ -134,6 +136,8 @@ SYMBOLS = {
     "vmx_device_count": (C.c_int, []),
     "vmx_default_spheres": (C.POINTER(Sphere), [C.POINTER(C.c_uint32)]),
     "vmx_scene_create": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "vmx_scene_create_ex": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                     C.POINTER(_P)]),
     "vmx_scene_destroy": (C.c_int, [_P]),
     "vmx_scene_bind_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vmx_scene_describe": (C.c_int, [_P, C.POINTER(SceneDesc)]),

@@ -28,4 +28,8 @@ struct HostBvh {
 bool build_bvh(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                uint32_t leaf_size, HostBvh &out, std::string &err);
 
+// binned-SAH quality builder (not the reference's topology; see bvh_build.cpp)
+bool build_bvh_sah(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
+                   uint32_t leaf_size, HostBvh &out, std::string &err);
+
 }  // namespace vmx

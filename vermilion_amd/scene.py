@@ -74,7 +74,7 @@ def default_spheres():
 class Scene:
     """Device-resident scene: replaces MeshEngine::createBVH + BVH for the HIP path."""
 
-    def __init__(self, pos, nrm, uv=None, spheres=None, leaf_size=4, device=0):
+    def __init__(self, pos, nrm, uv=None, spheres=None, leaf_size=4, device=0, builder=L.VMX_BVH_REFERENCE):
         pos = _f32(pos).reshape(-1, 9)
         nrm = _f32(nrm).reshape(-1, 9)
         if pos.shape != nrm.shape:
@@ -86,8 +86,8 @@ class Scene:
         self._spheres = spheres
         sp, nsp = (None, 0) if spheres is None else (C.addressof(spheres), len(spheres))
         h = C.c_void_p()
-        L.check(L.lib().vmx_scene_create(pos.ctypes.data, nrm.ctypes.data, uvp, pos.shape[0], sp, nsp,
-                                         int(leaf_size), int(device), C.byref(h)))
+        L.check(L.lib().vmx_scene_create_ex(pos.ctypes.data, nrm.ctypes.data, uvp, pos.shape[0], sp, nsp,
+                                            int(leaf_size), int(builder), int(device), C.byref(h)))
         self._h = h
         self.ntris = pos.shape[0]
         self.device = int(device)
