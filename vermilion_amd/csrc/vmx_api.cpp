@@ -502,12 +502,19 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     }
 
     // pass sizing: at most max_paths paths in flight
-    // paths in flight per pass: 128 M path slots = 11 GB of per-path state (288 GB of HBM per GPU);
-    // large passes keep the small late-bounce launches few
-    const uint64_t max_paths = opts->reserved[1] ? opts->reserved[1] : (128ull << 20);
+    // paths in flight per pass: up to 640 M path slots = 56 GB of per-path state (288 GB of HBM per
+    // GPU); large passes keep the small late-bounce launches few (16 M -> 640 M per pass: 1.8x on the
+    // whole frame).  Fixed-spp passes are balanced: ceil(kmax / passes) samples each.
+    // (the first-generation kernels move 96-byte records through two queues: 16 M paths there)
+    const uint64_t max_paths = opts->reserved[1] ? opts->reserved[1] : (legacy ? (16ull << 20) : (640ull << 20));
     uint32_t smax = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
     if (opts->samples_per_batch) smax = opts->samples_per_batch;
     smax = std::min(smax, fr.kmax);
+    if (fr.early_stop) smax = std::min(smax, fr.nmin + 1);  // larger groups are never issued under early stop
+    if (!fr.early_stop && !opts->samples_per_batch) {
+        const uint32_t npass = (fr.kmax + smax - 1) / smax;
+        smax = (fr.kmax + npass - 1) / npass;
+    }
     const uint32_t smax_alloc = smax;  // buffers are sized for this many samples per pixel and pass
 
     int pb = 1, bb = 1;
