@@ -312,7 +312,7 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.refill_min = o->reserved[3] ? o->reserved[3] : 16u;
     tn.refill_primary = o->reserved[3] ? o->reserved[3] : 64u;
     tn.shade_min = o->reserved[4] ? o->reserved[4] : 16u;
-    tn.leaf_min = o->reserved[5] ? o->reserved[5] : 16u;
+    tn.leaf_min = o->reserved[5] ? o->reserved[5] : 0xFFFFFFFFu;  // no vote (k_trace_q); k_paths treats it as 'majority'
     const uint32_t cap = o->reserved[6] ? o->reserved[6] : 10u;  // 11 x 512 B per wave: 28 waves/CU fit in 160 KiB
     tn.lds_entries = std::min(sc->dev.stack_entries, cap);
     tn.tail_threshold = o->reserved[2] ? o->reserved[2] : (512u << 10);
