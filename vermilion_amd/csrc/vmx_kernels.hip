@@ -1018,8 +1018,8 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
     for (;;) {
         // ---- 1. shade the lanes whose traversal is finished ---------------------
         {
-            const unsigned long long fin = __ballot(has && tdone);
-            const unsigned long long trav = __ballot(has && !tdone);
+            const unsigned long long fin = __builtin_amdgcn_ballot_w64(has && tdone);
+            const unsigned long long trav = __builtin_amdgcn_ballot_w64(has && !tdone);
             if (fin != 0 && ((uint32_t)__popcll(fin) >= wk.shade_min || trav == 0)) {
                 const bool shaded = has && tdone;
                 bool alive = false;
@@ -1047,7 +1047,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
         }
         // ---- 2. refill idle lanes from the work source ---------------------------
         {
-            const unsigned long long idle = __ballot(!has);
+            const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has);
             if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= wk.refill_min || idle == ~0ull)) {
                 for (;;) {
                     if (res_lo == res_hi) {
@@ -1069,7 +1069,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                         res_lo = base;
                         res_hi = min(base + kReserve, lim);
                     }
-                    const unsigned long long want = __ballot(!has);
+                    const unsigned long long want = __builtin_amdgcn_ballot_w64(!has);
                     if (want == 0) break;
                     const uint32_t avail = res_hi - res_lo;
                     const uint32_t rank = (uint32_t)__popcll(want & lt_mask);
@@ -1110,20 +1110,14 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                 }
             }
         }
-        if (__ballot(has) == 0) break;
-        // ---- 3. one traversal action for the wave (bvh.cpp:61-134) -----------------
-        // Lanes sit either at an inner node or at a leaf triangle.  Executing both
-        // branches every iteration wastes most lanes on incoherent rays (a few lanes at
-        // leaves, the rest at inner nodes), so the wave votes: the triangle step runs when
-        // the leaf lanes are the majority (or at least leaf_min), else the inner step; the
-        // other lanes wait.  Each lane's own sequence of tests is unchanged.
-        const bool trav = has && !tdone;
-        const bool at_leaf = trav && (cur & kLeafBit) != 0;
-        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
-        const uint32_t n_inner = (uint32_t)__popcll(__ballot(trav && !at_leaf));
-        bool need_next = false;  // this lane finished its node and must select the next one
-        bool carry = false;
-        if (n_leaf != 0 && (n_leaf >= n_inner || n_leaf >= wk.leaf_min)) {
+        if (__builtin_amdgcn_ballot_w64(has) == 0) break;
+        // ---- 3. up to 8 traversal actions (bvh.cpp:61-134): every traversing lane does its
+        //         triangle step or its inner-node step, then selects its next node --------------
+        for (int act = 0; act < 8; ++act) {
+            const bool trav = has && !tdone;
+            if (__builtin_amdgcn_ballot_w64(trav) == 0) break;
+            const bool at_leaf = trav && (cur & kLeafBit) != 0;
+            bool need_next = false, carry = false;
             if (at_leaf) {
                 // one triangle (triangle.cpp:4-54); the leaf ref itself carries the progress
                 const uint32_t ti = (cur & kLeafStartMask) * 3;
@@ -1152,10 +1146,9 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                     slot = (int)(cur & kLeafStartMask);
                 }
                 const uint32_t left = ((cur >> kLeafCountShift) & 31u) - 1u;
-                if (left == 0) need_next = true;
-                else cur = kLeafBit | (left << kLeafCountShift) | ((cur & kLeafStartMask) + 1u);
+                need_next = left == 0;
+                if (!need_next) cur = kLeafBit | (left << kLeafCountShift) | ((cur & kLeafStartMask) + 1u);
             }
-        } else if (n_inner != 0) {
             if (trav && !at_leaf) {
                 const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2],
                              q3 = inner[cur * 4 + 3];
@@ -1173,41 +1166,33 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                     h1 = box_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, P.ox, P.oy, P.oz, ix, iy, iz, tn1);
                 }
                 const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-                need_next = true;
-                if (h0 && h1) {
-                    const bool sw = tn1 < tn0;  // bvh.cpp:110
-                    const uint32_t other = sw ? lref : rref;
-                    const float no = sw ? tn0 : tn1;
-                    stack_push(stk, ovf, lds_entries, sp, make_uint2(other, __float_as_uint(no)));
+                const bool both = h0 && h1;  // bvh.cpp:103-132 without branches
+                const bool go_right = both ? (tn1 < tn0) : h1;
+                if (both) {
+                    stack_push(stk, ovf, lds_entries, sp,
+                               make_uint2(go_right ? lref : rref, __float_as_uint(go_right ? tn0 : tn1)));
                     ++sp;
-                    cur = sw ? rref : lref;
-                    cur_near = sw ? tn1 : tn0;
-                    carry = true;
-                } else if (h0) {
-                    cur = lref;
-                    cur_near = tn0;
-                    carry = true;
-                } else if (h1) {
-                    cur = rref;
-                    cur_near = tn1;
-                    carry = true;
                 }
+                cur = go_right ? rref : lref;
+                cur_near = go_right ? tn1 : tn0;
+                carry = h0 || h1;
+                need_next = true;
             }
-        }
-        if (need_next) {
-            // next node: the carried child, else pop until an entry passes `near > t` (bvh.cpp:69)
-            if (carry && cur_near > best) carry = false;
-            while (!carry) {
-                if (sp == 0) {
-                    tdone = true;
-                    break;
-                }
-                --sp;
-                const uint2 e = stack_pop(stk, ovf, lds_entries, sp);
-                if (!(__uint_as_float(e.y) > best)) {
-                    cur = e.x;
-                    cur_near = __uint_as_float(e.y);
-                    carry = true;
+            if (need_next) {
+                // next node: the carried child, else pop until an entry passes `near > t` (bvh.cpp:69)
+                if (carry && cur_near > best) carry = false;
+                while (!carry) {
+                    if (sp == 0) {
+                        tdone = true;
+                        break;
+                    }
+                    --sp;
+                    const uint2 e = stack_pop(stk, ovf, lds_entries, sp);
+                    if (!(__uint_as_float(e.y) > best)) {
+                        cur = e.x;
+                        cur_near = __uint_as_float(e.y);
+                        carry = true;
+                    }
                 }
             }
         }
