@@ -584,14 +584,16 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             } else {
                 // Past that point a pixel may stop after any sample.  While most pixels are still
                 // active one sample per pass is issued (nothing speculative); once the active set is
-                // small, up to 16 samples per pixel are issued at once and k_resolve discards what
-                // follows an early stop (same frame, fewer launch-bound passes).
+                // small, many samples per pixel are issued at once and k_resolve discards what
+                // follows an early stop (same frame, fewer launch-bound passes).  Pixels that keep
+                // sampling almost never stop later, so the speculation is deep (up to 8 M paths).
                 // Speculation only pays for pixels that keep sampling: it is used when fewer than
                 // 1 in 8 of the active pixels stopped a stratum in the previous pass.
-                const uint64_t spec = 1ull << 20;
+                const uint64_t spec = std::getenv("VMX_SPEC") ? std::strtoull(std::getenv("VMX_SPEC"), nullptr, 10) : (16ull << 20);
+                const uint64_t cap = std::getenv("VMX_SPEC_CAP") ? std::strtoull(std::getenv("VMX_SPEC_CAP"), nullptr, 10) : 1024;
                 S = 1;
                 if (last_pass_pixels > 0 && last_pass_breaks * 8 < last_pass_pixels)
-                    S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, spec / (2ull * n_active)), 16);
+                    S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, spec / (2ull * n_active)), cap);
                 S = (uint32_t)std::min<uint64_t>(S, ((uint64_t)n_pad_max * smax_alloc) / ((n_active + 63u) & ~63u));
                 S = std::max(S, 1u);
             }
