@@ -91,7 +91,9 @@ typedef struct vmx_opts {
     uint32_t samples_per_batch; /* fixed-spp mode: samples per pixel in flight per pass; 0 -> auto */
     uint32_t collect_counters;  /* 1: also count inner-node visits / triangle tests
                                    (instrumented kernels, slower; for roofline accounting) */
-    uint32_t reserved[7];
+    uint32_t reserved[7];  /* 0 unless tuning: [0] pipeline form, [1] max paths per pass, [2] tail threshold,
+                              [3] refill_min, [4] shade_min, [5] leaf_min, [6] LDS stack levels — all forms and
+                              settings produce the same frame (see vmx_api.cpp: render_impl, make_tuning) */
 } vmx_opts;
 
 /* per-stage figures: `primary` = Radiance steps taken at depth 0 (the fused

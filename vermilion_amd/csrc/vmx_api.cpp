@@ -494,19 +494,20 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
     const bool split_any = pipeline == 0 || pipeline == 4;
     const bool legacy = pipeline >= 2 && pipeline <= 3;
-    const uint64_t kHybridPaths = std::getenv("VMX_HYBRID") ? std::strtoull(std::getenv("VMX_HYBRID"), nullptr, 10) : (4ull << 20);
+    constexpr uint64_t kHybridPaths = 4ull << 20;  // measured: 1 M, 16 M and 64 M are all slower on early-stop frames
     const Tuning tn = make_tuning(sc, opts);
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
         return VMX_OK;
     }
 
-    // pass sizing: at most max_paths paths in flight
-    // paths in flight per pass: up to 640 M path slots = 56 GB of per-path state (288 GB of HBM per
+    // pass sizing — paths in flight per pass: up to 640 M path slots = 56 GB of per-path state (288 GB of HBM per
     // GPU); large passes keep the small late-bounce launches few (16 M -> 640 M per pass: 1.8x on the
     // whole frame).  Fixed-spp passes are balanced: ceil(kmax / passes) samples each.
     // (the first-generation kernels move 96-byte records through two queues: 16 M paths there)
-    const uint64_t max_paths = opts->reserved[1] ? opts->reserved[1] : (legacy ? (16ull << 20) : (640ull << 20));
+    // (path ids are 32-bit: never more than 2^31 slots per pass)
+    const uint64_t max_paths = std::min<uint64_t>(
+        opts->reserved[1] ? opts->reserved[1] : (legacy ? (16ull << 20) : (640ull << 20)), 1ull << 31);
     uint32_t smax = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
     if (opts->samples_per_batch) smax = opts->samples_per_batch;
     smax = std::min(smax, fr.kmax);
@@ -589,8 +590,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
                 // sampling almost never stop later, so the speculation is deep (up to 8 M paths).
                 // Speculation only pays for pixels that keep sampling: it is used when fewer than
                 // 1 in 8 of the active pixels stopped a stratum in the previous pass.
-                const uint64_t spec = std::getenv("VMX_SPEC") ? std::strtoull(std::getenv("VMX_SPEC"), nullptr, 10) : (16ull << 20);
-                const uint64_t cap = std::getenv("VMX_SPEC_CAP") ? std::strtoull(std::getenv("VMX_SPEC_CAP"), nullptr, 10) : 1024;
+                constexpr uint64_t spec = 16ull << 20, cap = 1024;  // measured: 45 ms -> 31 ms vs (1 M, 16)
                 S = 1;
                 if (last_pass_pixels > 0 && last_pass_breaks * 8 < last_pass_pixels)
                     S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, spec / (2ull * n_active)), cap);
