@@ -109,6 +109,7 @@ struct Workspace {
     DevBuf<unsigned char> overflow_stack;  // k_paths: stack levels beyond the LDS part
     DevBuf<unsigned char> rayA, rayB, rngA, rngB, hit, thr;  // split wavefront: per-path state
     DevBuf<unsigned int> ids[2], id_counts;             // split wavefront: live path ids
+    DevBuf<unsigned char> cam_inner, cam_tris;          // per-frame camera-relative scene tables
     DevBuf<unsigned char> rad;          // float4 per path of a pass
     DevBuf<unsigned char> accum;        // float4 per local pixel
     DevBuf<unsigned int> count, cursor, active[2], next_count;
@@ -120,7 +121,7 @@ struct Workspace {
     void release() {
         queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), heads.release(), overflow_stack.release();
         rayA.release(), rayB.release(), rngA.release(), rngB.release(), hit.release(), thr.release();
-        ids[0].release(), ids[1].release(), id_counts.release();
+        ids[0].release(), ids[1].release(), id_counts.release(), cam_inner.release(), cam_tris.release();
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
     }
@@ -564,6 +565,15 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
 
     HIP_TRY(hipMemcpyAsync(ws.active[0].p, ws.order.data(), (size_t)npix * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(ev0, s));
+    if (split_any) {
+        // camera-relative copies of the node and triangle records for this frame's origin
+        const size_t n_inner = std::max<size_t>(sc->bvh.inner.size(), 1);
+        if (ws.cam_inner.ensure(n_inner * 64) || ws.cam_tris.ensure((size_t)sc->ntris * 64))
+            return fail(VMX_ERR_NOMEM, "hipMalloc failed for the camera tables");
+        LAUNCH_TRY(launch_camera_tables(sc->dev, (uint32_t)sc->bvh.inner.size(), fr.px, fr.py, fr.pz, ws.cam_inner.p,
+                                        ws.cam_tris.p, s));
+        launches++;
+    }
     HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
     LAUNCH_TRY(launch_init_pixels(px, npix, s));
     launches++;
@@ -621,6 +631,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S;
             wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;
             wk.band_items = wk.band_slots * S;
+            wk.pixel_major = 1;
+            wk.cam_inner = ws.cam_inner.p, wk.cam_tris = ws.cam_tris.p;
             LaunchCfg cfg = paths_cfg(sc, tn, (uint64_t)n_pad * S, tb);
             rc = bind_stack(sc, tn, cfg.grid, wk);
             if (rc) return rc;
@@ -647,6 +659,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S;
             wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;
             wk.band_items = wk.band_slots * S;
+            wk.pixel_major = 1;
             LaunchCfg cfg = paths_cfg(sc, tn, (uint64_t)n_pad * S, rb);
             rc = bind_stack(sc, tn, cfg.grid, wk);
             if (rc) return rc;
@@ -672,7 +685,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             if (rc) return rc;
         }
         HIP_TRY(hipMemsetAsync(ws.next_count.p, 0, 8, s));
-        LAUNCH_TRY(launch_resolve(fr, ws.active[cur_list].p, n_active, S, ws.rad.p, px, ws.active[cur_list ^ 1].p,
+        LAUNCH_TRY(launch_resolve(fr, ws.active[cur_list].p, n_active, S, split || refill, ws.rad.p, px, ws.active[cur_list ^ 1].p,
                                   ws.next_count.p, d_out, ws.counters.p, s));
         launches++;
         passes++;

@@ -56,9 +56,13 @@ struct WorkDev {
     uint32_t n_active, n_pad, samples;
     uint32_t band_slots;        // slots per band (multiple of 64)
     uint32_t band_items;        // band_slots * samples
+    uint32_t pixel_major;       // 1: pid = slot * samples + j (samples of a pixel contiguous); 0: j * n_pad + slot
     // queue source
     QueueDev qin;     // first-generation kernels (96-byte path records)
     IdQueue qids;     // k_trace_q / k_shade / tail (path ids)
+    // camera rays: per-frame origin-relative node / triangle tables (k_camera_tables)
+    const void *cam_inner;  // float4[n_inner * 4]
+    const void *cam_tris;   // float4[ntris * 4]
 };
 
 struct LaunchCfg {
@@ -97,6 +101,8 @@ int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pixe
                  void *stream);
 int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks);
 // split wavefront: lean persistent trace kernel (vote-scheduled traversal, per-lane refill) ...
+int launch_camera_tables(const SceneDev &sc, uint32_t n_inner, float ox, float oy, float oz, void *cam_inner,
+                         void *cam_tris, void *stream);
 int launch_raygen(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
 int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                    DevCounters *counters, bool count, bool from_queue, LaunchCfg cfg, void *stream);
@@ -110,7 +116,7 @@ int launch_tail(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathA
 int launch_radiance_init_ids(const float *o, const float *d, uint32_t n, uint64_t seed, PathArrays pa,
                              IdQueue qout, void *stream);
 int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,
-                   const void *rad, PixelStateDev px, unsigned int *next_active,
+                   bool pixel_major, const void *rad, PixelStateDev px, unsigned int *next_active,
                    unsigned int *next_count, float *out_rgbaz, DevCounters *counters, void *stream);
 int launch_quantize(const float *frame, uint64_t npix, void *rgba8, float *depth, void *stream);
 int launch_assemble(const float *gathered, uint64_t rank_stride_floats, uint32_t width, uint32_t height,

@@ -165,6 +165,17 @@ __device__ __forceinline__ bool box_fast(float lx, float ly, float lz, float hx,
     tnear = n;
     return n <= f;
 }
+// Same with (lo - o), (hi - o) already formed (k_camera_tables)
+__device__ __forceinline__ bool box_fast_rel(float lx, float ly, float lz, float hx, float hy, float hz, float ix,
+                                             float iy, float iz, float &tnear) {
+    const float t0x = lx * ix, t0y = ly * iy, t0z = lz * iz;
+    const float t1x = hx * ix, t1y = hy * iy, t1z = hz * iz;
+    const float n = vmax3(vmin(t0x, t1x), vmin(t0y, t1y), vmin(t0z, t1z));
+    const float f = vmin3(vmax(t0x, t1x), vmax(t0y, t1y), vmax(t0z, t1z));
+    tnear = n;
+    return n <= f;
+}
+
 // Exact form: glm::min/max = (b<a)?b:a / (a<b)?b:a, std::max/min likewise, NaN and all.
 __device__ __forceinline__ float sel_min(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float sel_max(float a, float b) { return (a < b) ? b : a; }
@@ -173,6 +184,18 @@ __device__ __forceinline__ bool box_exact(float lx, float ly, float lz, float hx
                                        float &tnear) {
     const float t0x = (lx - ox) * ix, t0y = (ly - oy) * iy, t0z = (lz - oz) * iz;
     const float t1x = (hx - ox) * ix, t1y = (hy - oy) * iy, t1z = (hz - oz) * iz;
+    const float sx = sel_min(t0x, t1x), sy = sel_min(t0y, t1y), sz = sel_min(t0z, t1z);
+    const float bx = sel_max(t0x, t1x), by = sel_max(t0y, t1y), bz = sel_max(t0z, t1z);
+    const float n = sel_max(sel_max(sx, sy), sz);
+    const float f = sel_min(sel_min(bx, by), bz);
+    tnear = n;
+    return n <= f;
+}
+
+__device__ __forceinline__ bool box_exact_rel(float lx, float ly, float lz, float hx, float hy, float hz, float ix,
+                                              float iy, float iz, float &tnear) {
+    const float t0x = lx * ix, t0y = ly * iy, t0z = lz * iz;
+    const float t1x = hx * ix, t1y = hy * iy, t1z = hz * iz;
     const float sx = sel_min(t0x, t1x), sy = sel_min(t0y, t1y), sz = sel_min(t0z, t1z);
     const float bx = sel_max(t0x, t1x), by = sel_max(t0y, t1y), bz = sel_max(t0z, t1z);
     const float n = sel_max(sel_max(sx, sy), sz);
@@ -707,6 +730,13 @@ __device__ __forceinline__ void id_append(const IdQueue &q, uint32_t sub, bool a
     if (alive) q.ids[(size_t)sub * q.sub_capacity + base + rank] = pid;
 }
 
+// Path id of sample plane j of active-pixel slot s.  pixel_major: the samples of one pixel are
+// contiguous (pid = s * samples + j), so the 64 camera rays of a wave differ only by sub-pixel
+// jitter and walk the BVH together; else plane-major (pid = j * n_pad + s, first-generation kernels).
+__device__ __forceinline__ uint32_t path_id(const WorkDev &wk, uint32_t j, uint32_t s_idx) {
+    return wk.pixel_major ? s_idx * wk.samples + j : j * wk.n_pad + s_idx;
+}
+
 // band-local work item of the primary source -> path id, global pixel, sample index
 __device__ __forceinline__ bool primary_item(const FrameDev &fr, const WorkDev &wk, const PixelStateDev &px,
                                              uint32_t j, uint32_t s_idx, uint32_t &pid, uint32_t &pixel,
@@ -716,7 +746,7 @@ __device__ __forceinline__ bool primary_item(const FrameDev &fr, const WorkDev &
     k = px.cursor[lp] + j;
     if (k >= fr.kmax) return false;
     pixel = global_pixel(fr, lp);
-    pid = j * wk.n_pad + s_idx;
+    pid = path_id(wk, j, s_idx);
     return true;
 }
 
@@ -1079,8 +1109,13 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                     if (take) {
                         bool valid = true;
                         if (SRC == 0) {
-                            const uint32_t j = item / wk.band_slots;
-                            const uint32_t s_idx = src * wk.band_slots + (item - j * wk.band_slots);
+                            uint32_t j, s_idx;
+                            if (wk.pixel_major) {
+                                const uint32_t sl = item / wk.samples;
+                                j = item - sl * wk.samples, s_idx = src * wk.band_slots + sl;
+                            } else {
+                                j = item / wk.band_slots, s_idx = src * wk.band_slots + (item - j * wk.band_slots);
+                            }
                             valid = s_idx < wk.n_active;
                             if (valid) {
                                 const uint32_t lp = wk.active[s_idx];
@@ -1093,7 +1128,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                                     P.aw = -100.f;  // pathtracer.cpp:29
                                     P.tr = P.tg = P.tb = 1.f;  // :30
                                     P.depth = 0;
-                                    P.dest = j * wk.n_pad + s_idx;
+                                    P.dest = path_id(wk, j, s_idx);
                                 }
                             }
                         } else if (SRC == 1) {
@@ -1203,6 +1238,45 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
 
 
 
+
+// ---------------------------------------------------------------------------
+// k_camera_tables — every camera ray of a frame starts at the same origin, so
+// the origin-dependent half of both intersection tests is the same for all of
+// them.  Per frame this kernel writes copies of the node and triangle records
+// with that half applied:
+//   nodes : (lo - o), (hi - o) of both children     -> the slab test is 6 multiplies per box
+//   tris  : e1, e2, tvec = o - v0, qvec = cross(tvec, e1), C = dot(e2, qvec)
+// Each value is produced by the same float operation on the same inputs as the
+// per-ray code (bbox.cpp:72-73, triangle.cpp:30,36,42), so results stay bit-identical.
+// ---------------------------------------------------------------------------
+__global__ void k_camera_tables(SceneDev sc, uint32_t n_inner, float ox, float oy, float oz,
+                                float4 *__restrict__ cam_inner, float4 *__restrict__ cam_tris) {
+    const float4 *__restrict__ inner = (const float4 *)sc.inner;
+    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    const uint32_t total = n_inner + sc.ntris;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < n_inner) {
+            const float4 q0 = inner[i * 4], q1 = inner[i * 4 + 1], q2 = inner[i * 4 + 2], q3 = inner[i * 4 + 3];
+            cam_inner[i * 4] = make_float4(q0.x - ox, q0.y - oy, q0.z - oz, q0.w - ox);
+            cam_inner[i * 4 + 1] = make_float4(q1.x - oy, q1.y - oz, q1.z - ox, q1.w - oy);
+            cam_inner[i * 4 + 2] = make_float4(q2.x - oz, q2.y - ox, q2.z - oy, q2.w - oz);
+            cam_inner[i * 4 + 3] = q3;
+        } else {
+            const uint32_t t = i - n_inner;
+            const float4 a = tris[t * 3], b = tris[t * 3 + 1], c = tris[t * 3 + 2];
+            const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+            const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+            float qx, qy, qz;
+            cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+            const float cdot = dot3(e2x, e2y, e2z, qx, qy, qz);
+            cam_tris[t * 4] = make_float4(e1x, e1y, e1z, e2x);
+            cam_tris[t * 4 + 1] = make_float4(e2y, e2z, tx, ty);
+            cam_tris[t * 4 + 2] = make_float4(tz, qx, qy, qz);
+            cam_tris[t * 4 + 3] = make_float4(cdot, c.y, 0.f, 0.f);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // k_raygen — camera rays of one pass (pathtracer.cpp:251-280): ray of path
 // pid = j * n_pad + slot into rayA/rayB (depth 0).  Slots whose sample index is
@@ -1212,7 +1286,9 @@ __global__ void __launch_bounds__(256)
 k_raygen(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
     const uint32_t total = wk.samples * wk.n_pad;
     for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < total; pid += gridDim.x * blockDim.x) {
-        const uint32_t j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
+        uint32_t j, s_idx;
+        if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
+        else j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
         if (s_idx >= wk.n_active) continue;
         uint32_t pid2, pixel, k;
         float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -1244,8 +1320,9 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
     uint2 *stk = lds_stack + (size_t)wave * (lds_entries + 1) * 64 + lane;
     uint2 *ovf = (uint2 *)wk.overflow_stack +
                  ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * wk.overflow_entries) * 64 + lane;
-    const float4 *__restrict__ inner = (const float4 *)sc.inner;
-    const float4 *__restrict__ tris = (const float4 *)sc.tris;
+    // camera rays (SRC 0) read the per-frame origin-relative copies written by k_camera_tables
+    const float4 *__restrict__ inner = SRC == 0 ? (const float4 *)wk.cam_inner : (const float4 *)sc.inner;
+    const float4 *__restrict__ tris = SRC == 0 ? (const float4 *)wk.cam_tris : (const float4 *)sc.tris;
     float2 *__restrict__ hit_out = (float2 *)pa.hit;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     constexpr uint32_t kReserve = 256;
@@ -1298,10 +1375,15 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                     bool valid = true;
                     if (SRC == 0) {
                         // band-local item -> path id; the ray was written by k_raygen
-                        const uint32_t j = item / band_slots;
-                        const uint32_t s_idx = src * band_slots + (item - j * band_slots);
+                        uint32_t j, s_idx;
+                        if (wk.pixel_major) {
+                            const uint32_t sl = item / wk.samples;
+                            j = item - sl * wk.samples, s_idx = src * band_slots + sl;
+                        } else {
+                            j = item / band_slots, s_idx = src * band_slots + (item - j * band_slots);
+                        }
                         valid = s_idx < wk.n_active;
-                        pid = j * wk.n_pad + s_idx;
+                        pid = path_id(wk, j, s_idx);
                     } else {
                         pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
                     }
@@ -1346,23 +1428,37 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
             }
             bool need_next = false, carry = false;
             if (tri_turn && at_leaf) {
-                const uint32_t ti = (cur & kLeafStartMask) * 3;
-                const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
+                float det, inv_det, u, v, dist;
+                if (SRC == 0) {
+                    const uint32_t ti = (cur & kLeafStartMask) * 4;
+                    const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2], e = tris[ti + 3];
+                    // a = (e1, e2.x)  b = (e2.yz, tvec.xy)  c = (tvec.z, qvec)  e.x = dot(e2, qvec)
+                    float pvx, pvy, pvz;
+                    cross3(dx, dy, dz, a.w, b.x, b.y, pvx, pvy, pvz);
+                    det = dot3(a.x, a.y, a.z, pvx, pvy, pvz);
+                    inv_det = 1.0f / det;
+                    u = dot3(b.z, b.w, c.x, pvx, pvy, pvz) * inv_det;
+                    v = dot3(dx, dy, dz, c.y, c.z, c.w) * inv_det;
+                    dist = e.x * inv_det;
+                } else {
+                    const uint32_t ti = (cur & kLeafStartMask) * 3;
+                    const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
+                    const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+                    float pvx, pvy, pvz;
+                    cross3(dx, dy, dz, e2x, e2y, e2z, pvx, pvy, pvz);
+                    det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
+                    inv_det = 1.0f / det;
+                    const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+                    u = dot3(tx, ty, tz, pvx, pvy, pvz) * inv_det;
+                    float qx, qy, qz;
+                    cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+                    v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+                    dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+                }
                 if (COUNT && counted) cn.tris++;
-                const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
-                float pvx, pvy, pvz;
-                cross3(dx, dy, dz, e2x, e2y, e2z, pvx, pvy, pvz);
-                const float det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
                 const bool parallel = fabsf(det) <= 9.99999993922529e-09f;
-                const float inv_det = 1.0f / det;
-                const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
-                const float u = dot3(tx, ty, tz, pvx, pvy, pvz) * inv_det;
                 const bool u_out = (u < 0.0f) || (u > 1.0f);
-                float qx, qy, qz;
-                cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
-                const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
                 const bool v_out = (v < 0.0f) || (u + v > 1.0f);
-                const float dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
                 const bool hit = !parallel && !u_out && !v_out && (dist > 0.0f);
                 if (hit && dist < best) {  // strict <: first tested wins ties (bvh.cpp:90)
                     best = dist;
@@ -1373,12 +1469,36 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                 if (!need_next) cur = kLeafBit | (left << kLeafCountShift) | ((cur & kLeafStartMask) + 1u);
             }
             if (inner_turn && has && !at_leaf) {
-                const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2],
-                             q3 = inner[cur * 4 + 3];
+                // The kernel is bound by the vector-memory pipe (4 x 1 KiB per wave and node visit).
+                // Camera rays of one 8x8 tile mostly walk the same nodes: when every lane of this
+                // step is at the same node, the record is fetched once through the scalar cache.
+                float4 q0, q1, q2, q3;
+                const uint32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
+                if (SRC == 0 && __builtin_amdgcn_ballot_w64(cur != cur0) == 0) {
+                    // constant address space + wave-uniform address -> s_load_dwordx16
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    typedef const __attribute__((address_space(4))) f32x4 *scalar_ptr;
+                    const scalar_ptr rec = (scalar_ptr)(uintptr_t)(inner + (size_t)cur0 * 4);
+                    const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                    q0 = make_float4(r0.x, r0.y, r0.z, r0.w);
+                    q1 = make_float4(r1.x, r1.y, r1.z, r1.w);
+                    q2 = make_float4(r2.x, r2.y, r2.z, r2.w);
+                    q3 = make_float4(r3.x, r3.y, r3.z, r3.w);
+                } else {
+                    q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2], q3 = inner[cur * 4 + 3];
+                }
                 if (COUNT && counted) cn.inner++;
                 float tn0, tn1;
                 bool h0, h1;
-                if (exact) {
+                if (SRC == 0) {
+                    if (exact) {
+                        h0 = box_exact_rel(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ix, iy, iz, tn0);
+                        h1 = box_exact_rel(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ix, iy, iz, tn1);
+                    } else {
+                        h0 = box_fast_rel(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ix, iy, iz, tn0);
+                        h1 = box_fast_rel(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ix, iy, iz, tn1);
+                    }
+                } else if (exact) {
                     h0 = box_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, tn0);
                     h1 = box_exact(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, tn1);
                 } else {
@@ -1453,9 +1573,11 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
         Path P;
         if (SRC == 0) {
             pid = item * blockDim.x + threadIdx.x;
-            const uint32_t j = pid / wk.n_pad;
+            uint32_t j, s_idx;
+            if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
+            else j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
             uint32_t pixel = 0, k = 0, pid2;
-            run = j < wk.samples && primary_item(fr, wk, px, j, pid - j * wk.n_pad, pid2, pixel, k);
+            run = j < wk.samples && s_idx < wk.n_pad && primary_item(fr, wk, px, j, s_idx, pid2, pixel, k);
             if (run) {
                 // the ray comes from k_raygen; the stream is re-keyed and its two jitter draws skipped
                 ray_load(pa, pid, P);
@@ -1525,7 +1647,8 @@ __global__ void k_radiance_init_ids(const float *__restrict__ o, const float *__
 
 // per-pixel accumulation in sample order + early stop + pixel write (pathtracer.cpp:282-324)
 __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, uint32_t n_active,
-                          uint32_t n_pad, uint32_t samples, const float4 *__restrict__ rad, PixelStateDev px,
+                          uint32_t n_pad, uint32_t samples, uint32_t pixel_major, const float4 *__restrict__ rad,
+                          PixelStateDev px,
                           unsigned int *__restrict__ next_active, unsigned int *next_count,
                           float *__restrict__ out, DevCounters *ctr) {
     __shared__ unsigned int s_keep, s_base, s_taken, s_disc, s_done, s_brk;
@@ -1543,7 +1666,7 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
         for (uint32_t j = 0; j < samples; ++j) {
             const uint32_t k = cursor + j;
             if (k >= fr.kmax) break;
-            const float4 s = rad[(size_t)j * n_pad + slot];
+            const float4 s = rad[pixel_major ? (size_t)slot * samples + j : (size_t)j * n_pad + slot];
             ++n;  // :249
             acc.x = acc.x + s.x;  // :283
             acc.y = acc.y + s.y;
@@ -1756,6 +1879,16 @@ int launch_tail(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathA
     return launch_status();
 }
 
+int launch_camera_tables(const SceneDev &sc, uint32_t n_inner, float ox, float oy, float oz, void *cam_inner,
+                         void *cam_tris, void *stream) {
+    const uint32_t total = n_inner + sc.ntris;
+    uint32_t grid = std::min<uint32_t>((total + 255) / 256, 4096);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_camera_tables, dim3(grid), dim3(256), 0, (hipStream_t)stream, sc, n_inner, ox, oy, oz,
+                       (float4 *)cam_inner, (float4 *)cam_tris);
+    return launch_status();
+}
+
 int launch_raygen(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream) {
     const uint64_t total = (uint64_t)wk.samples * wk.n_pad;
     uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 32u);
@@ -1842,12 +1975,12 @@ int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, in
 }
 
 int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,
-                   const void *rad, PixelStateDev px, unsigned int *next_active, unsigned int *next_count,
-                   float *out_rgbaz, DevCounters *counters, void *stream) {
+                   bool pixel_major, const void *rad, PixelStateDev px, unsigned int *next_active,
+                   unsigned int *next_count, float *out_rgbaz, DevCounters *counters, void *stream) {
     const uint32_t n_pad = (n_active + 63u) & ~63u;
     hipLaunchKernelGGL(k_resolve, dim3((n_active + 255) / 256), dim3(256), 0, (hipStream_t)stream, fr, active,
-                       n_active, n_pad, samples, (const float4 *)rad, px, next_active, next_count, out_rgbaz,
-                       counters);
+                       n_active, n_pad, samples, pixel_major ? 1u : 0u, (const float4 *)rad, px, next_active,
+                       next_count, out_rgbaz, counters);
     return launch_status();
 }
 
