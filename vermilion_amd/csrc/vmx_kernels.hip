@@ -999,6 +999,9 @@ __device__ __forceinline__ void stack_push(uint2 *stk, uint2 *ovf, int lds_entri
 }
 __device__ __forceinline__ uint2 stack_pop(const uint2 *stk, const uint2 *ovf, int lds_entries, int sp) {
     uint2 e = stk[min(sp, lds_entries) * 64];
+    // the empty asm pins the LDS read as its own ds_read_b64: without it the two loads are merged
+    // into one flat load through a pointer select, which puts every pop on the vector-memory pipe
+    asm volatile("" : "+v"(e.x), "+v"(e.y));
     if (sp >= lds_entries) e = ovf[(sp - lds_entries) * 64];
     return e;
 }
