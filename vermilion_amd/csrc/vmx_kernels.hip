@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "vmx_kernels.h"
+#include <type_traits>
 
 #ifndef VMX_TRACE_WAVES_PER_SIMD
 #define VMX_TRACE_WAVES_PER_SIMD 7  // register budget of the trace kernel: 512 / 7 -> 72 VGPRs
@@ -1553,6 +1554,256 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 }
 
 // ---------------------------------------------------------------------------
+// k_trace_w — k_trace_q's production form (no counters, no vote), written for the
+// limit the SQ counters show this loop runs at: instruction delivery.  One
+// traversal step of the first form executed ~62 VALU + ~47 SALU + ~12 branch
+// instructions, and the instruction cache two CUs share was busy ~100 % of the
+// kernel's cycles (SQC_ICACHE_BUSY_CYCLES; profiles/).  This form issues fewer of them:
+//   * lane state is the node reference alone (idle = kIdle, "must pop" = kPop, bit 31 = leaf):
+//     no has/carry/need_next lane masks to merge with SALU triples at every join;
+//   * the stack has a virtual bottom entry (ref kBottom, near = -inf): the pop loop
+//     is a single do-while on `near > best` and a finished ray falls out of it;
+//   * the NaN-exact box form is chosen per wave (a wave with any such ray runs the
+//     exact form for all its lanes — both forms agree on finite data), not per lane;
+//   * the min/max network of a box is one asm block (no hazard nops between the
+//     pieces) and a scalar-fetched node record is multiplied straight from SGPRs;
+//   * the all-lanes-idle test is made once per 8 steps, not every step.
+// Each ray still performs exactly the reference's sequence of tests (bvh.cpp:47-145).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void box_net(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z,
+                                        float &tnear, float &tfar) {
+    float n, f, s1, s2;
+    asm("v_min_f32 %0, %4, %7\n\t"
+        "v_min_f32 %2, %5, %8\n\t"
+        "v_min_f32 %3, %6, %9\n\t"
+        "v_max3_f32 %0, %0, %2, %3\n\t"
+        "v_max_f32 %1, %4, %7\n\t"
+        "v_max_f32 %2, %5, %8\n\t"
+        "v_max_f32 %3, %6, %9\n\t"
+        "v_min3_f32 %1, %1, %2, %3"
+        : "=&v"(n), "=&v"(f), "=&v"(s1), "=&v"(s2)
+        : "v"(t0x), "v"(t0y), "v"(t0z), "v"(t1x), "v"(t1y), "v"(t1z));
+    tnear = n;
+    tfar = f;
+}
+__device__ __forceinline__ void box_net_exact(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z,
+                                              float &tnear, float &tfar) {
+    const float sx = sel_min(t0x, t1x), sy = sel_min(t0y, t1y), sz = sel_min(t0z, t1z);
+    const float bx = sel_max(t0x, t1x), by = sel_max(t0y, t1y), bz = sel_max(t0z, t1z);
+    tnear = sel_max(sel_max(sx, sy), sz);
+    tfar = sel_min(sel_min(bx, by), bz);
+}
+
+template <int SRC>
+__global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD)
+k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const int lds_entries = (int)wk.lds_entries;
+    uint2 *stk = lds_stack + (size_t)wave * (lds_entries + 1) * 64 + lane;
+    uint2 *ovf = (uint2 *)wk.overflow_stack +
+                 ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * wk.overflow_entries) * 64 + lane;
+    const float4 *__restrict__ inner = SRC == 0 ? (const float4 *)wk.cam_inner : (const float4 *)sc.inner;
+    const float4 *__restrict__ tris = SRC == 0 ? (const float4 *)wk.cam_tris : (const float4 *)sc.tris;
+    float2 *__restrict__ hit_out = (float2 *)pa.hit;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    constexpr uint32_t kReserve = 256;
+    constexpr uint32_t kIdle = 0x7FFFFFFFu, kBottom = 0x7FFFFFFEu, kPop = 0x7FFFFFFDu;  // never valid inner indices
+    const uint32_t nsrc = wk.nsrc, refill_min = wk.refill_min;
+    const uint32_t band_slots = wk.band_slots, band_items = wk.band_items;
+    const uint32_t root_ref = sc.root_ref;
+
+    uint32_t src = blockIdx.x % nsrc, res_lo = 0, res_hi = 0, tried = 0;
+    bool exhausted = false;
+    bool exact = false;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    float ix = 0.f, iy = 0.f, iz = 0.f, best = 0.f;
+    int slot = -1, sp = 0;
+    uint32_t cur = kIdle, pid = 0;
+
+    // one traversal step of every active lane; EXACT selects the box form for the whole wave
+    auto step = [&](auto exact_tag) {
+        constexpr bool EXACT = decltype(exact_tag)::value;
+        if ((int)cur < 0) {
+            // ---- one triangle of the leaf (triangle.cpp:4-54); the ref itself carries the progress
+            float det, inv_det, u, v, dist;
+            if (SRC == 0) {
+                const uint32_t ti = (cur & kLeafStartMask) * 4;
+                const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
+                const float cd = ((const float *)tris)[ti * 4 + 12];
+                // a = (e1, e2.x)  b = (e2.yz, tvec.xy)  c = (tvec.z, qvec)  cd = dot(e2, qvec)
+                float pvx, pvy, pvz;
+                cross3(dx, dy, dz, a.w, b.x, b.y, pvx, pvy, pvz);
+                det = dot3(a.x, a.y, a.z, pvx, pvy, pvz);
+                inv_det = 1.0f / det;
+                u = dot3(b.z, b.w, c.x, pvx, pvy, pvz) * inv_det;
+                v = dot3(dx, dy, dz, c.y, c.z, c.w) * inv_det;
+                dist = cd * inv_det;
+            } else {
+                const uint32_t ti = (cur & kLeafStartMask) * 3;
+                const float4 a = tris[ti], b = tris[ti + 1];
+                const float e2z = ((const float *)tris)[ti * 4 + 8];
+                const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w;
+                float pvx, pvy, pvz;
+                cross3(dx, dy, dz, e2x, e2y, e2z, pvx, pvy, pvz);
+                det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
+                inv_det = 1.0f / det;
+                const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+                u = dot3(tx, ty, tz, pvx, pvy, pvz) * inv_det;
+                float qx, qy, qz;
+                cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+                v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+                dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+            }
+            const bool parallel = fabsf(det) <= 9.99999993922529e-09f;
+            const bool u_out = (u < 0.0f) || (u > 1.0f);
+            const bool v_out = (v < 0.0f) || (u + v > 1.0f);
+            const bool hit = !parallel && !u_out && !v_out && (dist > 0.0f);
+            if (hit && dist < best) {  // strict <: first tested wins ties (bvh.cpp:90)
+                best = dist;
+                slot = (int)(cur & kLeafStartMask);
+            }
+            // next triangle: start + 1, count - 1; after the last one the lane pops
+            cur = (((cur >> kLeafCountShift) & 31u) == 1u) ? kPop : cur + (1u - (1u << kLeafCountShift));
+        } else if (cur != kIdle) {
+            // ---- inner node: both children boxes (bbox.cpp:70-83), nearer child first (bvh.cpp:103-132)
+            float tn0, tf0, tn1, tf1;
+            uint32_t lref, rref;
+            const uint32_t cur0 = __builtin_amdgcn_readfirstlane(cur);
+            if (SRC == 0 && !EXACT && __builtin_amdgcn_ballot_w64(cur != cur0) == 0) {
+                // every lane of this step is at the same node: one fetch through the scalar cache,
+                // and the products take the record straight from SGPRs
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(4))) f32x4 *scalar_ptr;
+                const scalar_ptr rec = (scalar_ptr)(uintptr_t)(inner + (size_t)cur0 * 4);
+                const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                box_net(r0.x * ix, r0.y * iy, r0.z * iz, r0.w * ix, r1.x * iy, r1.y * iz, tn0, tf0);
+                box_net(r1.z * ix, r1.w * iy, r2.x * iz, r2.y * ix, r2.z * iy, r2.w * iz, tn1, tf1);
+                lref = __float_as_uint(r3.x), rref = __float_as_uint(r3.y);
+            } else {
+                const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2];
+                const float2 q3 = ((const float2 *)inner)[cur * 8 + 6];
+                float a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;
+                if (SRC == 0) {
+                    a0 = q0.x * ix, a1 = q0.y * iy, a2 = q0.z * iz, a3 = q0.w * ix, a4 = q1.x * iy, a5 = q1.y * iz;
+                    b0 = q1.z * ix, b1 = q1.w * iy, b2 = q2.x * iz, b3 = q2.y * ix, b4 = q2.z * iy, b5 = q2.w * iz;
+                } else {
+                    a0 = (q0.x - ox) * ix, a1 = (q0.y - oy) * iy, a2 = (q0.z - oz) * iz;
+                    a3 = (q0.w - ox) * ix, a4 = (q1.x - oy) * iy, a5 = (q1.y - oz) * iz;
+                    b0 = (q1.z - ox) * ix, b1 = (q1.w - oy) * iy, b2 = (q2.x - oz) * iz;
+                    b3 = (q2.y - ox) * ix, b4 = (q2.z - oy) * iy, b5 = (q2.w - oz) * iz;
+                }
+                if (EXACT) {
+                    box_net_exact(a0, a1, a2, a3, a4, a5, tn0, tf0);
+                    box_net_exact(b0, b1, b2, b3, b4, b5, tn1, tf1);
+                } else {
+                    box_net(a0, a1, a2, a3, a4, a5, tn0, tf0);
+                    box_net(b0, b1, b2, b3, b4, b5, tn1, tf1);
+                }
+                lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+            }
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            const bool both = h0 && h1;
+            const bool go_right = h1 && (!h0 || (tn1 < tn0));  // both: the strictly closer right child; one: that child
+            if (both) {
+                stack_push(stk, ovf, lds_entries, sp,
+                           make_uint2(go_right ? lref : rref, __float_as_uint(go_right ? tn0 : tn1)));
+                ++sp;
+            }
+            const float near = go_right ? tn1 : tn0;
+            // no child hit, or the child taken directly fails `near > t` (bvh.cpp:69): pop
+            cur = (!(h0 || h1) || (near > best)) ? kPop : (go_right ? rref : lref);
+        }
+        if (cur == kPop) {
+            // pop until an entry passes `near > t` (bvh.cpp:69); below the last entry lies the
+            // virtual bottom entry, which always passes and ends the ray
+            uint2 e;
+            do {
+                --sp;
+                e = stack_pop(stk, ovf, lds_entries, max(sp, 0));
+                if (sp < 0) e = make_uint2(kBottom, 0xFF800000u);
+            } while (__uint_as_float(e.y) > best);
+            cur = e.x;
+            if (cur == kBottom) {
+                hit_out[pid] = make_float2(best, __int_as_float(slot));
+                cur = kIdle;
+            }
+        }
+    };
+
+    for (;;) {
+        // ---- refill idle lanes -------------------------------------------------------
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(cur == kIdle);
+        if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= refill_min || idle == ~0ull)) {
+            for (;;) {
+                if (res_lo == res_hi) {
+                    const uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&wk.heads[src * 32], kReserve);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= lim) {
+                        src = (src + 1 == nsrc) ? 0 : src + 1;
+                        if (++tried == nsrc) {
+                            exhausted = true;
+                            break;
+                        }
+                        continue;
+                    }
+                    tried = 0;
+                    res_lo = base;
+                    res_hi = min(base + kReserve, lim);
+                }
+                const unsigned long long want = __builtin_amdgcn_ballot_w64(cur == kIdle);
+                if (want == 0) break;
+                const uint32_t avail = res_hi - res_lo;
+                const uint32_t rank = (uint32_t)__popcll(want & lt_mask);
+                const bool take = cur == kIdle && rank < avail;
+                const uint32_t item = res_lo + rank;
+                res_lo = __builtin_amdgcn_readfirstlane(res_lo + min((uint32_t)__popcll(want), avail));
+                if (take) {
+                    bool valid = true;
+                    if (SRC == 0) {
+                        uint32_t j, s_idx;
+                        if (wk.pixel_major) {
+                            const uint32_t sl = item / wk.samples;
+                            j = item - sl * wk.samples, s_idx = src * band_slots + sl;
+                        } else {
+                            j = item / band_slots, s_idx = src * band_slots + (item - j * band_slots);
+                        }
+                        valid = s_idx < wk.n_active;
+                        pid = path_id(wk, j, s_idx);
+                    } else {
+                        pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
+                    }
+                    if (valid) {
+                        const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
+                        ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
+                        valid = __float_as_uint(b.z) != 0xFFFFFFFFu;  // sample slot past the pixel's last sample
+                    }
+                    if (valid) {
+                        ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // Ray.h:10
+                        exact = !(finite3(ix, iy, iz) && finite3(ox, oy, oz));
+                        best = 999999999.f;  // bvh.cpp:48
+                        slot = -1;
+                        sp = 0;
+                        cur = root_ref;  // its near value, -9999999 (bvh.cpp:59), passes `near > t`
+                    }
+                }
+            }
+        }
+        const unsigned long long active = __builtin_amdgcn_ballot_w64(cur != kIdle);
+        if (active == 0) break;
+        if (__builtin_amdgcn_ballot_w64(exact && cur != kIdle) != 0) {
+#pragma unroll 1
+            for (int act = 0; act < 8; ++act) step(std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int act = 0; act < 8; ++act) step(std::false_type{});
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_shade — the wide shading kernel of the split wavefront: the part of
 // MeshEngine::RayCast after the BVH query (triangle normal, sphere table,
 // meshEngine.cpp:365-508) and one iteration of Radiance's loop
@@ -1908,9 +2159,9 @@ int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pi
     const bool vote = wk.leaf_min != 0xFFFFFFFFu;
     const int sel = (count ? 4 : 0) | (from_queue ? 2 : 0) | (vote ? 1 : 0);
     switch (sel) {
-        case 0: VMX_GO(false, 0, false); break;
+        case 0: hipLaunchKernelGGL((k_trace_w<0>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa); break;
         case 1: VMX_GO(false, 0, true); break;
-        case 2: VMX_GO(false, 1, false); break;
+        case 2: hipLaunchKernelGGL((k_trace_w<1>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa); break;
         case 3: VMX_GO(false, 1, true); break;
         case 4: VMX_GO(true, 0, false); break;
         case 5: VMX_GO(true, 0, true); break;
@@ -1928,8 +2179,8 @@ int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, 
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 0, false>, (int)block, lds_bytes);
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_q<true, 1, false>, (int)block, lds_bytes);
     } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<false, 0, false>, (int)block, lds_bytes);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_q<false, 1, false>, (int)block, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_w<0>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_w<1>, (int)block, lds_bytes);
     }
     if (blocks) *blocks = a < b ? a : b;
     return (int)e;
