@@ -313,7 +313,7 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.refill_min = o->reserved[3] ? o->reserved[3] : 16u;
     tn.refill_primary = o->reserved[3] ? o->reserved[3] : 64u;
     tn.shade_min = o->reserved[4] ? o->reserved[4] : 16u;
-    tn.leaf_min = o->reserved[5] ? o->reserved[5] : 0xFFFFFFFFu;  // no vote (k_trace_q); k_paths treats it as 'majority'
+    tn.leaf_min = o->reserved[5] ? o->reserved[5] : 0xFFFFFFFFu;  // k_paths only: triangle-step vote (default: majority)
     const uint32_t cap = o->reserved[6] ? o->reserved[6] : 10u;  // 11 x 512 B per wave: 28 waves/CU fit in 160 KiB
     tn.lds_entries = std::min(sc->dev.stack_entries, cap);
     tn.tail_threshold = o->reserved[2] ? o->reserved[2] : (512u << 10);
@@ -326,7 +326,8 @@ constexpr uint32_t kPathsBlock = 256;
 int bind_stack(vmx_scene *sc, const Tuning &tn, uint32_t grid, WorkDev &wk) {
     wk.lds_entries = tn.lds_entries;
     wk.leaf_min = tn.leaf_min;
-    wk.overflow_entries = sc->dev.stack_entries > tn.lds_entries ? sc->dev.stack_entries - tn.lds_entries : 1u;
+    // + 1: k_trace_w keeps its bottom entry in LDS level 0
+    wk.overflow_entries = sc->dev.stack_entries + 1 > tn.lds_entries ? sc->dev.stack_entries + 1 - tn.lds_entries : 1u;
     const size_t waves = (size_t)grid * (kPathsBlock / 64);
     if (sc->ws.overflow_stack.ensure(waves * wk.overflow_entries * 64 * 8))
         return fail(VMX_ERR_NOMEM, "hipMalloc failed for the overflow stack");

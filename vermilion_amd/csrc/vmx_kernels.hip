@@ -1315,7 +1315,7 @@ k_raygen(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
 //   SRC 0: primary rays, generated from (pixel, sample) — origin is uniform
 //   SRC 1: bounce rays of the queued path ids, read from rayA/rayB
 // ---------------------------------------------------------------------------
-template <bool COUNT, int SRC, bool VOTE>
+template <bool COUNT, int SRC>
 __global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD)
 k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, DevCounters *ctr) {
     extern __shared__ uint2 lds_stack[];
@@ -1331,7 +1331,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     constexpr uint32_t kReserve = 256;
     constexpr int kActionsPerCheck = 8;  // traversal actions between two scheduling checks
-    const uint32_t nsrc = wk.nsrc, refill_min = wk.refill_min, leaf_min = wk.leaf_min;
+    const uint32_t nsrc = wk.nsrc, refill_min = wk.refill_min;
     const uint32_t band_slots = wk.band_slots, band_items = wk.band_items;
     const uint32_t root_ref = sc.root_ref;
 
@@ -1413,25 +1413,13 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
         }
         if (__builtin_amdgcn_ballot_w64(has) == 0) break;
         // ---- traversal actions --------------------------------------------------------------
-        // VOTE: the wave votes between the one-triangle step and the inner-node step (the majority,
-        // or >= leaf_min leaf lanes, runs; the others wait).  !VOTE: both steps every iteration.
-        // Measured on the Sponza stand-in: no vote is 8 % faster for camera rays and equal for
-        // bounce rays, so it is the default; each lane's own sequence of tests is the same either way.
+        // every iteration runs the one-triangle step for the lanes at a leaf and the inner-node step
+        // for the others (a vote between the two was measured and is no faster)
         for (int act = 0; act < kActionsPerCheck; ++act) {
             const bool at_leaf = has && (cur & kLeafBit) != 0;
-            bool tri_turn = true, inner_turn = true;
-            if (VOTE) {
-                const unsigned long long m_leaf = __builtin_amdgcn_ballot_w64(at_leaf);
-                const unsigned long long m_inner = __builtin_amdgcn_ballot_w64(has && !at_leaf);
-                if ((m_leaf | m_inner) == 0) break;
-                const uint32_t n_leaf = (uint32_t)__popcll(m_leaf), n_inner = (uint32_t)__popcll(m_inner);
-                tri_turn = n_leaf >= n_inner || n_leaf >= leaf_min;
-                inner_turn = !tri_turn;
-            } else {
-                if (__builtin_amdgcn_ballot_w64(has) == 0) break;
-            }
+            if (__builtin_amdgcn_ballot_w64(has) == 0) break;
             bool need_next = false, carry = false;
-            if (tri_turn && at_leaf) {
+            if (at_leaf) {
                 float det, inv_det, u, v, dist;
                 if (SRC == 0) {
                     const uint32_t ti = (cur & kLeafStartMask) * 4;
@@ -1472,7 +1460,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                 need_next = left == 0;
                 if (!need_next) cur = kLeafBit | (left << kLeafCountShift) | ((cur & kLeafStartMask) + 1u);
             }
-            if (inner_turn && has && !at_leaf) {
+            if (has && !at_leaf) {
                 // The kernel is bound by the vector-memory pipe (4 x 1 KiB per wave and node visit).
                 // Camera rays of one 8x8 tile mostly walk the same nodes: when every lane of this
                 // step is at the same node, the record is fetched once through the scalar cache.
@@ -1561,8 +1549,8 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 // kernel's cycles (SQC_ICACHE_BUSY_CYCLES; profiles/).  This form issues fewer of them:
 //   * lane state is the node reference alone (idle = kIdle, "must pop" = kPop, bit 31 = leaf):
 //     no has/carry/need_next lane masks to merge with SALU triples at every join;
-//   * the stack has a virtual bottom entry (ref kBottom, near = -inf): the pop loop
-//     is a single do-while on `near > best` and a finished ray falls out of it;
+//   * stack level 0 holds a bottom entry (ref kBottom, near = -inf): the pop loop is a
+//     single do-while on `near > best` and a finished ray falls out of it;
 //   * the NaN-exact box form is chosen per wave (a wave with any such ray runs the
 //     exact form for all its lanes — both forms agree on finite data), not per lane;
 //   * the min/max network of a box is one asm block (no hazard nops between the
@@ -1620,10 +1608,12 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     float ix = 0.f, iy = 0.f, iz = 0.f, best = 0.f;
     int slot = -1, sp = 0;
     uint32_t cur = kIdle, pid = 0;
+    stk[0] = make_uint2(kBottom, 0xFF800000u);  // bottom entry; pushes start at level 1, so it stays
 
-    // one traversal step of every active lane; EXACT selects the box form for the whole wave
+    // One traversal step of every active lane.  The NaN-exact box form runs only while one of the
+    // wave's rays needs it.
     auto step = [&](auto exact_tag) {
-        constexpr bool EXACT = decltype(exact_tag)::value;
+        constexpr bool EXACT = decltype(exact_tag)::value;  // NaN-exact box form
         if ((int)cur < 0) {
             // ---- one triangle of the leaf (triangle.cpp:4-54); the ref itself carries the progress
             float det, inv_det, u, v, dist;
@@ -1706,8 +1696,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             const bool both = h0 && h1;
             const bool go_right = h1 && (!h0 || (tn1 < tn0));  // both: the strictly closer right child; one: that child
             if (both) {
-                stack_push(stk, ovf, lds_entries, sp,
-                           make_uint2(go_right ? lref : rref, __float_as_uint(go_right ? tn0 : tn1)));
+                const uint2 e = make_uint2(go_right ? lref : rref, __float_as_uint(go_right ? tn0 : tn1));
+                stack_push(stk, ovf, lds_entries, sp, e);
                 ++sp;
             }
             const float near = go_right ? tn1 : tn0;
@@ -1715,13 +1705,12 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             cur = (!(h0 || h1) || (near > best)) ? kPop : (go_right ? rref : lref);
         }
         if (cur == kPop) {
-            // pop until an entry passes `near > t` (bvh.cpp:69); below the last entry lies the
-            // virtual bottom entry, which always passes and ends the ray
+            // pop until an entry passes `near > t` (bvh.cpp:69); level 0 holds the bottom entry
+            // (near = -inf), which always passes and ends the ray
             uint2 e;
             do {
                 --sp;
-                e = stack_pop(stk, ovf, lds_entries, max(sp, 0));
-                if (sp < 0) e = make_uint2(kBottom, 0xFF800000u);
+                e = stack_pop(stk, ovf, lds_entries, sp);
             } while (__uint_as_float(e.y) > best);
             cur = e.x;
             if (cur == kBottom) {
@@ -1785,7 +1774,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                         exact = !(finite3(ix, iy, iz) && finite3(ox, oy, oz));
                         best = 999999999.f;  // bvh.cpp:48
                         slot = -1;
-                        sp = 0;
+                        sp = 1;
                         cur = root_ref;  // its near value, -9999999 (bvh.cpp:59), passes `near > t`
                     }
                 }
@@ -1917,26 +1906,46 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
         uint32_t n = px.count[lp];
         const uint32_t cursor = px.cursor[lp];
         uint32_t next = cursor + samples;
-        for (uint32_t j = 0; j < samples; ++j) {
-            const uint32_t k = cursor + j;
-            if (k >= fr.kmax) break;
-            const float4 s = rad[pixel_major ? (size_t)slot * samples + j : (size_t)j * n_pad + slot];
-            ++n;  // :249
-            acc.x = acc.x + s.x;  // :283
-            acc.y = acc.y + s.y;
-            acc.z = acc.z + s.z;
-            ++taken;
-            if (fr.early_stop && n > fr.nmin) {  // n > sqrt(spp), :292
-                const float fn = (float)n, fn1 = (float)(n + 1);
-                const float ex = acc.x / fn - (acc.x + s.x) / fn1;
-                const float ey = acc.y / fn - (acc.y + s.y) / fn1;
-                const float ez = acc.z / fn - (acc.z + s.z) / fn1;
-                if (fabsf(sqrtf(dot3(ex, ey, ez, ex, ey, ez))) < 0.00001f) {
-                    next = (k / fr.quarter + 1u) * fr.quarter;  // break the innermost loop only
-                    const uint32_t last = cursor + samples < fr.kmax ? cursor + samples : fr.kmax;
-                    disc = last - (k + 1);
-                    brk = 1;
-                    break;
+        // samples are taken strictly in order (float sums, early stop), but their loads need not
+        // wait for each other: fetch 8 at a time (pixel-major: one 128-byte line per lane)
+        constexpr uint32_t kChunk = 8;
+        const size_t total = (size_t)n_pad * samples;
+        bool stop = false;
+        for (uint32_t j0 = 0; j0 < samples && !stop; j0 += kChunk) {
+            float4 buf[kChunk];
+#pragma unroll
+            for (uint32_t i = 0; i < kChunk; ++i) {
+                const uint32_t j = j0 + i;
+                size_t idx = pixel_major ? (size_t)slot * samples + j : (size_t)j * n_pad + slot;
+                if (j >= samples || idx >= total) idx = (size_t)slot;  // any valid address; value unused
+                buf[i] = rad[idx];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kChunk; ++i) {
+                const uint32_t j = j0 + i;
+                const uint32_t k = cursor + j;
+                if (stop || j >= samples || k >= fr.kmax) {
+                    stop = true;
+                    continue;
+                }
+                const float4 s = buf[i];
+                ++n;  // :249
+                acc.x = acc.x + s.x;  // :283
+                acc.y = acc.y + s.y;
+                acc.z = acc.z + s.z;
+                ++taken;
+                if (fr.early_stop && n > fr.nmin) {  // n > sqrt(spp), :292
+                    const float fn = (float)n, fn1 = (float)(n + 1);
+                    const float ex = acc.x / fn - (acc.x + s.x) / fn1;
+                    const float ey = acc.y / fn - (acc.y + s.y) / fn1;
+                    const float ez = acc.z / fn - (acc.z + s.z) / fn1;
+                    if (fabsf(sqrtf(dot3(ex, ey, ez, ex, ey, ez))) < 0.00001f) {
+                        next = (k / fr.quarter + 1u) * fr.quarter;  // break the innermost loop only
+                        const uint32_t last = cursor + samples < fr.kmax ? cursor + samples : fr.kmax;
+                        disc = last - (k + 1);
+                        brk = 1;
+                        stop = true;
+                    }
                 }
             }
         }
@@ -2155,20 +2164,14 @@ int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pi
                    DevCounters *counters, bool count, bool from_queue, LaunchCfg cfg, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     dim3 g(cfg.grid), b(cfg.block);
-#define VMX_GO(C, S, V) hipLaunchKernelGGL((k_trace_q<C, S, V>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, pa, counters)
-    const bool vote = wk.leaf_min != 0xFFFFFFFFu;
-    const int sel = (count ? 4 : 0) | (from_queue ? 2 : 0) | (vote ? 1 : 0);
-    switch (sel) {
-        case 0: hipLaunchKernelGGL((k_trace_w<0>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa); break;
-        case 1: VMX_GO(false, 0, true); break;
-        case 2: hipLaunchKernelGGL((k_trace_w<1>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa); break;
-        case 3: VMX_GO(false, 1, true); break;
-        case 4: VMX_GO(true, 0, false); break;
-        case 5: VMX_GO(true, 0, true); break;
-        case 6: VMX_GO(true, 1, false); break;
-        default: VMX_GO(true, 1, true); break;
+    // production form: k_trace_w; with counters: the first form k_trace_q (same tests per ray)
+    if (!count) {
+        if (from_queue) hipLaunchKernelGGL((k_trace_w<1>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
+        else hipLaunchKernelGGL((k_trace_w<0>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
+    } else {
+        if (from_queue) hipLaunchKernelGGL((k_trace_q<true, 1>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, pa, counters);
+        else hipLaunchKernelGGL((k_trace_q<true, 0>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, pa, counters);
     }
-#undef VMX_GO
     return launch_status();
 }
 
@@ -2176,8 +2179,8 @@ int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, 
     int a = 0, b = 0;
     hipError_t e;
     if (count) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 0, false>, (int)block, lds_bytes);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_q<true, 1, false>, (int)block, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 0>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_q<true, 1>, (int)block, lds_bytes);
     } else {
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_w<0>, (int)block, lds_bytes);
         if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_w<1>, (int)block, lds_bytes);
