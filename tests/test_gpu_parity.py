@@ -111,6 +111,9 @@ def test_radiance_paths_bit_exact(pair, sampling):
     assert st["primary"]["inner_visits"] + st["bounce"]["inner_visits"] == rst["primary"]["inner_visits"]
     assert st["primary"]["tri_tests"] + st["bounce"]["tri_tests"] == rst["primary"]["tri_tests"]
     assert st["primary"]["tri_hits"] + st["bounce"]["tri_hits"] == rst["primary"]["tri_hits"]
+    # production kernels (no counters: k_trace_w) give the same paths
+    rad2, st2 = pair.gpu.radiance(o, d, va.make_opts(seed=5, sampling=sampling))
+    assert np.array_equal(bits(rad2), bits(rrad)) and st2["rays_secondary"] == rst["rays_secondary"]
 
 
 @pytest.mark.parametrize("early_stop,sampling", [(1, 0), (0, 0), (1, 1), (0, 1)])
@@ -185,6 +188,14 @@ def test_special_rays_nan_slabs_ties_and_degenerates():
     rtri, rt = p.cpu.trace(oo, dd)
     assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
     assert_raycast_equal(p.gpu.raycast(oo, dd), p.cpu.raycast(oo, dd))
+    # whole paths from these rays: the traversal kernel of the render path takes its NaN-exact route
+    for sampling in (0, 1):
+        for kw in ({}, {"lds_entries": 1}, {"collect_counters": True}):
+            opts = va.make_opts(seed=9, sampling=sampling, **kw)
+            rad, st = p.gpu.radiance(oo, dd, opts)
+            rrad, rst = p.cpu.radiance(oo, dd, opts)
+            assert np.all(same_f32(rad, rrad)), (sampling, kw)
+            assert st["rays_secondary"] == rst["rays_secondary"]
     p.close()
 
 
