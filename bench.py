@@ -170,7 +170,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world == 1 and (W, H, spp, args.scene) == (1920, 1080, 256, "sponza260k"):
             try:
-                traffic = json.load(open(tpath)).get("k_trace_q_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("trace_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         total_rays_frame = cst["rays_primary"] + cst["rays_secondary"]
@@ -196,7 +196,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_trace_q<SRC=primary> (persistent BVH traversal of the depth-0 rays)",
+                "kernel": "k_trace_w<0> (persistent BVH traversal of the depth-0 rays)",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

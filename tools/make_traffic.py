@@ -1,8 +1,7 @@
 """profiles/traffic.json from the PMC passes of tools/pmc.sh (gpurun_out/pmc_<tag>_N).
 
 Picks, in every pass, the longest launch of the camera-ray traversal kernel
-(k_trace_q<false, 0, false> — the single 256-samples-per-pixel launch of the
-fixed-spp frame) and records its counters.  HBM bytes follow
+(k_trace_w<0> — the single 256-samples-per-pixel launch of the fixed-spp frame) and records its counters.  HBM bytes follow
 MI355X_MICROARCH.md's HBM section: FETCH_SIZE and WRITE_SIZE are collected in
 separate --pmc passes, are in KiB, and FETCH_SIZE is doubled on gfx950 for
 16-byte-per-lane loads (128-B requests tallied at 64 B).
@@ -16,7 +15,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "k_trace_q<false, 0, false>"
+KERNEL = "k_trace_w<0>"
 
 
 def longest_launch(pass_dir):
@@ -60,7 +59,7 @@ def main():
         "WRITE_SIZE_KB_per_launch": c["WRITE_SIZE"],
         "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16-B-per-lane loads, "
                       "MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as read; separate --pmc passes; KB -> bytes x1024",
-        "k_trace_q_hbm_bytes_per_launch": int(fetch + write),
+        "trace_kernel_hbm_bytes_per_launch": int(fetch + write),
         "algorithmic_bytes_per_launch": alg,
         "expected_stream_bytes": f"32-B ray read + 8-B hit write per ray = {rays * 40 / 1e9:.1f} GB",
         "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
@@ -70,9 +69,9 @@ def main():
         "vmem_read_insts_per_launch": c["SQ_INSTS_VMEM_RD"],
         "lds_insts_per_launch": c["SQ_INSTS_LDS"],
         "valu_lane_utilization": lanes / (valu * 64),
-        # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count in units of 4 cycles, summed over waves: the
-        # fraction of a SIMD's time its VALU is issuing = active / (wave_cycles / waves-per-SIMD)
-        "valu_busy_frac_of_simd_time": c["SQ_ACTIVE_INST_VALU"] / (c["SQ_WAVE_CYCLES"] / 7.0),
+        # wave-level instruction counts per ray: what the loop's cost is made of
+        "valu_wave_insts_per_64_rays": valu / (rays / 64),
+        "salu_wave_insts_per_64_rays": c["SQ_INSTS_SALU"] / (rays / 64),
         "valu_lane_ops_per_ray": lanes / rays,
         "wait_any_frac_per_wave": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
         "avg_ms_under_pmc": sum(ms) / len(ms),
