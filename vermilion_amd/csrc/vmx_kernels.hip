@@ -739,12 +739,24 @@ __device__ __forceinline__ uint32_t path_id(const WorkDev &wk, uint32_t j, uint3
 }
 
 // band-local work item of the primary source -> path id, global pixel, sample index
+// Sample index of the j-th path a pixel gets in this pass.  Bit 31 of the cursor marks a pixel whose
+// last stratum ended on the early-stop rule (pathtracer.cpp:290-311): it will most likely end the
+// following strata on their first sample too, so its paths of a pass are the first samples of the
+// next strata (k = cursor + j * quarter) instead of consecutive samples; k_resolve takes them in
+// order and drops what the rule would not have reached.
+constexpr uint32_t kCursorStrided = 0x80000000u;
+__device__ __forceinline__ uint32_t sample_index(const FrameDev &fr, const PixelStateDev &px, uint32_t lp,
+                                                 uint32_t j) {
+    const uint32_t c = px.cursor[lp];
+    return (c & ~kCursorStrided) + j * ((c & kCursorStrided) ? fr.quarter : 1u);
+}
+
 __device__ __forceinline__ bool primary_item(const FrameDev &fr, const WorkDev &wk, const PixelStateDev &px,
                                              uint32_t j, uint32_t s_idx, uint32_t &pid, uint32_t &pixel,
                                              uint32_t &k) {
     if (s_idx >= wk.n_active) return false;
     const uint32_t lp = wk.active[s_idx];
-    k = px.cursor[lp] + j;
+    k = sample_index(fr, px, lp, j);
     if (k >= fr.kmax) return false;
     pixel = global_pixel(fr, lp);
     pid = path_id(wk, j, s_idx);
@@ -866,7 +878,7 @@ __global__ void k_primary(SceneDev sc, FrameDev fr, const unsigned int *__restri
         uint32_t lp = 0;
         if (run) {
             lp = active[slot];
-            const uint32_t k = px.cursor[lp] + j;
+            const uint32_t k = sample_index(fr, px, lp, j);
             run = k < fr.kmax;
             if (run) {
                 const uint32_t p = global_pixel(fr, lp);
@@ -1123,7 +1135,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                             valid = s_idx < wk.n_active;
                             if (valid) {
                                 const uint32_t lp = wk.active[s_idx];
-                                const uint32_t k = px.cursor[lp] + j;
+                                const uint32_t k = sample_index(fr, px, lp, j);
                                 valid = k < fr.kmax;
                                 if (valid) {
                                     primary_ray(fr, global_pixel(fr, lp), k, P.rng, P.dx, P.dy, P.dz);
@@ -1904,8 +1916,13 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
         lp = active[slot];
         float4 acc = ((float4 *)px.accum)[lp];
         uint32_t n = px.count[lp];
-        const uint32_t cursor = px.cursor[lp];
-        uint32_t next = cursor + samples;
+        const uint32_t craw = px.cursor[lp];
+        const uint32_t cursor = craw & ~kCursorStrided;
+        // strided: this pass's paths are the first samples of the following strata (sample_index)
+        const bool strided = (craw & kCursorStrided) != 0;
+        const uint32_t stride = strided ? fr.quarter : 1u;
+        uint32_t next = cursor + samples * stride;
+        bool flag = strided;  // still in a run of early stops unless a sample says otherwise
         // samples are taken strictly in order (float sums, early stop), but their loads need not
         // wait for each other: fetch 8 at a time (pixel-major: one 128-byte line per lane)
         constexpr uint32_t kChunk = 8;
@@ -1923,7 +1940,7 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
 #pragma unroll
             for (uint32_t i = 0; i < kChunk; ++i) {
                 const uint32_t j = j0 + i;
-                const uint32_t k = cursor + j;
+                const uint32_t k = cursor + j * stride;
                 if (stop || j >= samples || k >= fr.kmax) {
                     stop = true;
                     continue;
@@ -1934,18 +1951,30 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
                 acc.y = acc.y + s.y;
                 acc.z = acc.z + s.z;
                 ++taken;
+                bool early = false;
                 if (fr.early_stop && n > fr.nmin) {  // n > sqrt(spp), :292
                     const float fn = (float)n, fn1 = (float)(n + 1);
                     const float ex = acc.x / fn - (acc.x + s.x) / fn1;
                     const float ey = acc.y / fn - (acc.y + s.y) / fn1;
                     const float ez = acc.z / fn - (acc.z + s.z) / fn1;
-                    if (fabsf(sqrtf(dot3(ex, ey, ez, ex, ey, ez))) < 0.00001f) {
-                        next = (k / fr.quarter + 1u) * fr.quarter;  // break the innermost loop only
-                        const uint32_t last = cursor + samples < fr.kmax ? cursor + samples : fr.kmax;
-                        disc = last - (k + 1);
-                        brk = 1;
+                    early = fabsf(sqrtf(dot3(ex, ey, ez, ex, ey, ez))) < 0.00001f;
+                }
+                // number of this pass's paths that come after sample j
+                uint32_t later = samples - 1u - j;
+                if (cursor + (samples - 1u) * stride >= fr.kmax) later = (fr.kmax - 1u - k) / stride;
+                if (early) {
+                    brk = 1;
+                    next = (k / fr.quarter + 1u) * fr.quarter;  // break the innermost loop only
+                    flag = true;
+                    if (!strided) {  // the rest of this pass's consecutive samples is not taken
+                        disc = later;
                         stop = true;
                     }
+                } else if (strided) {  // this stratum goes on with sample k + 1; later strata were not due yet
+                    next = k + 1u;
+                    flag = false;
+                    disc = later;
+                    stop = true;
                 }
             }
         }
@@ -1963,7 +1992,7 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
         }
         ((float4 *)px.accum)[lp] = acc;
         px.count[lp] = n;
-        px.cursor[lp] = next;
+        px.cursor[lp] = next | ((flag && next < fr.kmax) ? kCursorStrided : 0u);
     }
     // block-aggregated append to the next active list
     uint32_t my = 0;
