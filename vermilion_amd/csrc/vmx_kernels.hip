@@ -334,19 +334,48 @@ __device__ __forceinline__ void tri_shading_normal(const SceneDev &sc, int slot,
     normalize3(nx, ny, nz);
 }
 
-// sphereIntersect (meshEngine.cpp:182-194): float dots, float rad*rad, double discriminant
+// sphereIntersect (meshEngine.cpp:182-194): float dots, float rad*rad, double discriminant.
+// The caller only uses a result in (0, limit) (limit = RayCast's nearest distance so far), and the
+// double-precision part (discriminant, square root, two roots: ~75 f64 instructions per sphere, 8
+// spheres per RayCast) was more than half of the shading kernels' time.  Three single-precision
+// tests on the same float dot products B = op.d, C = op.op and R2 = rad*rad the reference forms
+// decide, with a margin far above every rounding error involved (2^-20 relative against 2^-24 float
+// and 2^-53 double steps), that the double-precision result cannot matter:
+//   miss   : B^2 < (C - R2) - tol                 =>  det < 0, the reference returns 0
+//   behind : B < 0 and C >= R2                    =>  det <= fl(B^2), both roots <= 1e-4 (for |B| < 1e11): returns 0
+//   far    : B > limit and (C - R2) - limit (2B - limit) > tol  =>  det < (B - limit)^2 (1 - 2^-40),
+//            so the smaller root rounds to >= limit and the caller ignores it
+// Only lanes that pass none of them need the exact evaluation; a wave runs it if any lane does (the
+// 64 camera rays of a wave belong to one pixel and mostly agree).
 __device__ __forceinline__ float sphere_hit(float ox, float oy, float oz, float dx, float dy, float dz,
-                                            const SphereDev &s) {
-    const float opx = s.cx - ox, opy = s.cy - oy, opz = s.cz - oz;
-    const double b = (double)dot3(opx, opy, opz, dx, dy, dz);
-    double det = b * b - (double)dot3(opx, opy, opz, opx, opy, opz) + (double)s.rad2;
-    if (det < 0) return 0.f;
-    det = sqrt(det);
-    double t = b - det;
-    if (t > 1e-4) return (float)t;
-    t = b + det;
-    if (t > 1e-4) return (float)t;
-    return 0.f;
+                                            float4 geom /* centre, rad*rad */, float limit) {
+    const float opx = geom.x - ox, opy = geom.y - oy, opz = geom.z - oz;
+    const float B = dot3(opx, opy, opz, dx, dy, dz), C = dot3(opx, opy, opz, opx, opy, opz), R2 = geom.w;
+    const float X = C - R2, BB = B * B;
+    constexpr float kRel = 9.5367431640625e-07f;  // 2^-20
+    const float tol_m = kRel * (C + R2 + BB);
+    const float tol_f = kRel * (C + R2 + BB + limit * (2.f * fabsf(B) + limit));
+    const bool miss = BB < X - tol_m;
+    const bool behind = B < 0.f && B > -1e11f && C >= R2;
+    const bool far = B > limit * (1.f + kRel) && (X - limit * (2.f * B - limit)) > tol_f;
+    const bool need = !(miss || behind || far);
+    float th = 0.f;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+        const double b = (double)B;
+        double det = b * b - (double)C + (double)R2;
+        float v = 0.f;
+        if (!(det < 0)) {
+            det = sqrt(det);
+            double t = b - det;
+            if (t > 1e-4) v = (float)t;
+            else {
+                t = b + det;
+                if (t > 1e-4) v = (float)t;
+            }
+        }
+        th = need ? v : 0.f;
+    }
+    return th;
 }
 
 struct CastResult {
@@ -360,8 +389,12 @@ struct CastResult {
 };
 
 // MeshEngine::RayCast after the BVH query (meshEngine.cpp:365-508): triangle normal, sphere table
+// `geom`: optional copy of the spheres' (centre, rad*rad) in LDS (k_shade) — every path tests every
+// sphere, the rest of a sphere's record is read only when it becomes the nearest hit
+constexpr uint32_t kLdsSpheres = 16;
 __device__ __forceinline__ void cast_finish(const SceneDev &sc, float ox, float oy, float oz, float dx,
-                                            float dy, float dz, float best, int slot, CastResult &r) {
+                                            float dy, float dz, float best, int slot, CastResult &r,
+                                            const float4 *geom = nullptr) {
     r.nearest = kInf;
     r.nx = r.ny = r.nz = 0.f;
     r.cr = r.cg = r.cb = 0.f;
@@ -377,9 +410,16 @@ __device__ __forceinline__ void cast_finish(const SceneDev &sc, float ox, float 
     }
     const uint32_t ns = sc.nspheres;
     for (uint32_t i = 0; i < ns; ++i) {
-        const SphereDev s = sc.spheres[i];
-        const float th = sphere_hit(ox, oy, oz, dx, dy, dz, s);
+        float4 g;
+        if (geom != nullptr && i < kLdsSpheres) {
+            g = geom[i];
+        } else {
+            const SphereDev &q = sc.spheres[i];
+            g = make_float4(q.cx, q.cy, q.cz, q.rad2);
+        }
+        const float th = sphere_hit(ox, oy, oz, dx, dy, dz, g, r.nearest);
         if (th > 0.f && th < r.nearest) {
+            const SphereDev s = sc.spheres[i];
             r.nearest = th;
             if (s.flags & 1u) {
                 r.cr = s.colr;
@@ -439,12 +479,33 @@ __device__ __forceinline__ float4 tex_sample(const SceneDev &sc, float u, float 
     }
 }
 
+// The loop body is split where the cosine-lobe branch needs cos/sin of r1 (double precision, a few
+// hundred instructions): only ~10 % of the paths get there (the others end, or bounce off the
+// mirror lobe), so k_shade gathers those angles of a whole block and evaluates them in full waves.
+struct ShadeMid {
+    float sx, sy, sz;  // origin of the next ray
+    float r2s, q;      // sqrt(r2), sqrt(1 - r2)
+    double angle;      // r1
+};
+enum { kPathEnded = 0, kPathNextRay = 1, kPathNeedsTrig = 2 };
+
+__device__ __forceinline__ bool path_set_ray(Path &P, StepFlags &fl, float sx, float sy, float sz, float ndx, float ndy,
+                                             float ndz) {
+    P.ox = sx, P.oy = sy, P.oz = sz;
+    P.dx = ndx, P.dy = ndy, P.dz = ndz;
+    // An all-NaN direction (r2 > 1, pathtracer.cpp:156-162) misses the BVH and
+    // every sphere in RayCast, so Radiance returns accumColour: end the path here.
+    if ((ndx != ndx) && (ndy != ndy) && (ndz != ndz)) return false;
+    fl.continues = finite3(ndx, ndy, ndz);
+    return true;
+}
+
 template <bool TEX>
-__device__ __forceinline__ bool path_shade(const SceneDev &sc, float r2scale, Path &P, const CastResult &c,
-                                           StepFlags &fl) {
+__device__ __forceinline__ int path_shade_begin(const SceneDev &sc, float r2scale, Path &P, const CastResult &c,
+                                                StepFlags &fl, ShadeMid &m) {
     fl.tri_hit = c.slot >= 0;
     fl.continues = false;
-    if (!(c.nearest < kInf)) return false;  // pathtracer.cpp:36-41
+    if (!(c.nearest < kInf)) return kPathEnded;  // pathtracer.cpp:36-41
     if (TEX) {  // :43
         P.ar = P.ar + P.tr * c.cr;
         P.ag = P.ag + P.tg * c.cg;
@@ -457,16 +518,15 @@ __device__ __forceinline__ bool path_shade(const SceneDev &sc, float r2scale, Pa
         P.ab = P.ab + c.cb;
     }
     if (P.depth == 0) P.aw = c.nearest;                                   // :44-47
-    if (sqrtf(dot3(c.cr, c.cg, c.cb, c.cr, c.cg, c.cb)) > 1.f) return false;  // :52
+    if (sqrtf(dot3(c.cr, c.cg, c.cb, c.cr, c.cg, c.cb)) > 1.f) return kPathEnded;  // :52
     P.depth++;
     if (P.depth > 5) {  // :56 — the draw happens only past depth 5
         const double rr = rng_u01(P.rng);
-        if (rr > (double)0.95f || P.depth > 1000) return false;
+        if (rr > (double)0.95f || P.depth > 1000) return kPathEnded;
     }
     // hit location and back-off along the incoming ray (:108,163,189)
     const float lx = P.ox + (P.dx * c.nearest), ly = P.oy + (P.dy * c.nearest), lz = P.oz + (P.dz * c.nearest);
-    const float sx = lx - P.dx * 0.001f, sy = ly - P.dy * 0.001f, sz = lz - P.dz * 0.001f;
-    float ndx, ndy, ndz;
+    m.sx = lx - P.dx * 0.001f, m.sy = ly - P.dy * 0.001f, m.sz = lz - P.dz * 0.001f;
     bool specular = false;
     if (c.material) specular = rng_u01(P.rng) >= 0.96;  // :98
     if (specular) {
@@ -474,61 +534,67 @@ __device__ __forceinline__ bool path_shade(const SceneDev &sc, float r2scale, Pa
         (void)rng_next(P.rng);
         (void)rng_next(P.rng);  // unused noise, :101-103
         const float k = dot3(c.nx, c.ny, c.nz, P.dx, P.dy, P.dz);
-        ndx = P.dx - c.nx * 2.f * k;
-        ndy = P.dy - c.ny * 2.f * k;
-        ndz = P.dz - c.nz * 2.f * k;
+        float ndx = P.dx - c.nx * 2.f * k;
+        float ndy = P.dy - c.ny * 2.f * k;
+        float ndz = P.dz - c.nz * 2.f * k;
         normalize3(ndx, ndy, ndz);
-    } else {
-        float r2s, cs, sn, q;
-        if (c.material) {  // :151-165
-            if (TEX) {  // accumRadiance *= sampleColour (:153), sampled at the BVH hit's uv (:63-66)
-                const float4 tx = tex_sample(sc, c.uvx, c.uvy);
-                P.tr = P.tr * tx.x;
-                P.tg = P.tg * tx.y;
-                P.tb = P.tb * tx.z;
-            }
-            const float r1 = (float)(6.283185307179586 * rng_u01(P.rng));
-            const float r2 = (float)((double)r2scale * rng_u01(P.rng));
-            r2s = sqrtf(r2);
-            cs = (float)cos((double)r1);
-            sn = (float)sin((double)r1);
-            q = sqrtf(1.0f - r2);
-        } else {  // :166-196 — nearest hit is a sphere and the BVH hit nothing
-            const double r1 = 6.283185307179586 * rng_u01(P.rng);
-            const double r2 = (double)r2scale * rng_u01(P.rng);
-            r2s = (float)sqrt(r2);
-            (void)rng_next(P.rng);
-            (void)rng_next(P.rng);
-            (void)rng_next(P.rng);  // :173-175
-            cs = (float)cos(r1);
-            sn = (float)sin(r1);
-            q = (float)sqrt(1.0 - r2);
-        }
-        const bool facing = dot3(c.nx, c.ny, c.nz, P.dx, P.dy, P.dz) < 0.f;
-        const float wx = facing ? c.nx : c.nx * -1.f, wy = facing ? c.ny : c.ny * -1.f,
-                    wz = facing ? c.nz : c.nz * -1.f;
-        const bool use_y = (double)fabsf(wx) > .1;
-        const float ax = use_y ? 0.f : 1.f, ay = use_y ? 1.f : 0.f, az = 0.f;
-        float ux, uy, uz, vx, vy, vz;
-        cross3(ax, ay, az, wx, wy, wz, ux, uy, uz);
-        normalize3(ux, uy, uz);
-        cross3(wx, wy, wz, ux, uy, uz, vx, vy, vz);
-        ndx = (ux * cs * r2s + vx * sn * r2s) + wx * q;
-        ndy = (uy * cs * r2s + vy * sn * r2s) + wy * q;
-        ndz = (uz * cs * r2s + vz * sn * r2s) + wz * q;
-        normalize3(ndx, ndy, ndz);
+        return path_set_ray(P, fl, m.sx, m.sy, m.sz, ndx, ndy, ndz) ? kPathNextRay : kPathEnded;
     }
-    P.ox = sx;
-    P.oy = sy;
-    P.oz = sz;
-    P.dx = ndx;
-    P.dy = ndy;
-    P.dz = ndz;
-    // An all-NaN direction (r2 > 1, pathtracer.cpp:156-162) misses the BVH and
-    // every sphere in RayCast, so Radiance returns accumColour: end the path here.
-    if ((ndx != ndx) && (ndy != ndy) && (ndz != ndz)) return false;
-    fl.continues = finite3(ndx, ndy, ndz);
-    return true;
+    if (c.material) {  // :151-165
+        if (TEX) {  // accumRadiance *= sampleColour (:153), sampled at the BVH hit's uv (:63-66)
+            const float4 tx = tex_sample(sc, c.uvx, c.uvy);
+            P.tr = P.tr * tx.x;
+            P.tg = P.tg * tx.y;
+            P.tb = P.tb * tx.z;
+        }
+        const float r1 = (float)(6.283185307179586 * rng_u01(P.rng));
+        const float r2 = (float)((double)r2scale * rng_u01(P.rng));
+        m.r2s = sqrtf(r2);
+        m.angle = (double)r1;
+        m.q = sqrtf(1.0f - r2);
+    } else {  // :166-196 — nearest hit is a sphere and the BVH hit nothing
+        const double r1 = 6.283185307179586 * rng_u01(P.rng);
+        const double r2 = (double)r2scale * rng_u01(P.rng);
+        m.r2s = (float)sqrt(r2);
+        (void)rng_next(P.rng);
+        (void)rng_next(P.rng);
+        (void)rng_next(P.rng);  // :173-175
+        m.angle = r1;
+        m.q = (float)sqrt(1.0 - r2);
+    }
+    // r2 > 1 (9 draws in 10 with the reference's r2 = 10 U): q is NaN, so every component of
+    // (u cs r2s + v sn r2s) + w q is NaN whatever cos and sin are, and the path ends (path_set_ray)
+    if (m.q != m.q) return kPathEnded;
+    return kPathNeedsTrig;
+}
+
+// second half of the cosine-lobe branch (pathtracer.cpp:158-165,176-196): cs = (float)cos(r1), sn = (float)sin(r1)
+__device__ __forceinline__ bool path_shade_end(Path &P, const CastResult &c, StepFlags &fl, const ShadeMid &m, float cs,
+                                               float sn) {
+    const bool facing = dot3(c.nx, c.ny, c.nz, P.dx, P.dy, P.dz) < 0.f;
+    const float wx = facing ? c.nx : c.nx * -1.f, wy = facing ? c.ny : c.ny * -1.f,
+                wz = facing ? c.nz : c.nz * -1.f;
+    const bool use_y = (double)fabsf(wx) > .1;
+    const float ax = use_y ? 0.f : 1.f, ay = use_y ? 1.f : 0.f, az = 0.f;
+    float ux, uy, uz, vx, vy, vz;
+    cross3(ax, ay, az, wx, wy, wz, ux, uy, uz);
+    normalize3(ux, uy, uz);
+    cross3(wx, wy, wz, ux, uy, uz, vx, vy, vz);
+    float ndx = (ux * cs * m.r2s + vx * sn * m.r2s) + wx * m.q;
+    float ndy = (uy * cs * m.r2s + vy * sn * m.r2s) + wy * m.q;
+    float ndz = (uz * cs * m.r2s + vz * sn * m.r2s) + wz * m.q;
+    normalize3(ndx, ndy, ndz);
+    return path_set_ray(P, fl, m.sx, m.sy, m.sz, ndx, ndy, ndz);
+}
+
+// Radiance's loop body after RayCast in one piece (the fused kernels)
+template <bool TEX>
+__device__ __forceinline__ bool path_shade(const SceneDev &sc, float r2scale, Path &P, const CastResult &c,
+                                           StepFlags &fl) {
+    ShadeMid m;
+    const int st = path_shade_begin<TEX>(sc, r2scale, P, c, fl, m);
+    if (st != kPathNeedsTrig) return st == kPathNextRay;
+    return path_shade_end(P, c, fl, m, (float)cos(m.angle), (float)sin(m.angle));
 }
 
 template <bool COUNT>
@@ -1820,6 +1886,16 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
         DevCounters *ctr) {
     const float2 *__restrict__ hits = (const float2 *)pa.hit;
     float4 *__restrict__ rad = (float4 *)pa.rad;
+    __shared__ double s_angle[256];
+    __shared__ float s_cs[256], s_sn[256];
+    __shared__ unsigned int s_ntrig;
+    __shared__ float4 s_geom[kLdsSpheres];
+    if (threadIdx.x == 0) s_ntrig = 0;
+    if (threadIdx.x < min(sc.nspheres, kLdsSpheres)) {
+        const SphereDev &q = sc.spheres[threadIdx.x];
+        s_geom[threadIdx.x] = make_float4(q.cx, q.cy, q.cz, q.rad2);
+    }
+    __syncthreads();
     Tally tl = {{0, 0}, {0, 0}, {0, 0}};
     const uint32_t items = SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues;
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -1853,23 +1929,46 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             }
         }
         StepFlags fl = {false, false, false};
-        bool alive = false;
         uint32_t depth0 = 0;
+        int st = kPathEnded;
+        ShadeMid mid;
+        CastResult c;
         if (run) {
             P.dest = pid;
             depth0 = P.depth == 0 ? 1u : 0u;
             fl.was_ray = depth0 ? true : finite3(P.dx, P.dy, P.dz);
             const float2 h = hits[pid];
-            CastResult c;
-            cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c);
-            alive = path_shade<TEX>(sc, fr.r2scale, P, c, fl);
+            cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom);
+            st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
             rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
-            if (alive) {
-                ray_store(pa, pid, P);
-                rng_store(pa, pid, P.rng);
-                if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, 1.f);
-            }
         }
+        // gather the block's angles, evaluate cos/sin in full waves, hand the values back
+        const bool trig = st == kPathNeedsTrig;
+        uint32_t tslot = 0;
+        {
+            const unsigned long long m = __ballot(trig);
+            uint32_t base = 0;
+            if (m != 0 && lane_index() == 0) base = atomicAdd(&s_ntrig, (uint32_t)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            tslot = base + (uint32_t)__popcll(m & ((1ull << lane_index()) - 1ull));
+            if (trig) s_angle[tslot] = mid.angle;
+        }
+        __syncthreads();
+        if (threadIdx.x < s_ntrig) {
+            const double a = s_angle[threadIdx.x];
+            s_cs[threadIdx.x] = (float)cos(a);
+            s_sn[threadIdx.x] = (float)sin(a);
+        }
+        __syncthreads();
+        bool alive = st == kPathNextRay;
+        if (trig) alive = path_shade_end(P, c, fl, mid, s_cs[tslot], s_sn[tslot]);
+        if (alive) {
+            ray_store(pa, pid, P);
+            rng_store(pa, pid, P.rng);
+            if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, 1.f);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_ntrig = 0;
         tally_add(tl, fl, run, depth0);
         id_append(qout, item % kSubQueues, alive, pid);
     }
