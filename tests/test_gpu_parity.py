@@ -204,6 +204,33 @@ def test_special_rays_nan_slabs_ties_and_degenerates():
     p.close()
 
 
+def test_sphere_table_rays_starting_on_the_walls():
+    """bounce rays start 0.001 off the surface they left, often one of the 5e7-radius wall spheres:
+    there (B*B - C) + R2 cancels at the magnitude of C, the case every shortcut around the
+    double-precision solve (kernels: sphere_hit) has to get right"""
+    rng = np.random.default_rng(7)
+    n = 60000
+    oo, dd = [], []
+    for ax, val in ((0, -2000), (0, 2000), (2, -2000), (2, 2000), (1, 0), (1, 1000)):
+        o = np.empty((n, 3), np.float32)
+        o[:, 0], o[:, 1], o[:, 2] = rng.uniform(-2000, 2000, n), rng.uniform(0, 1000, n), rng.uniform(-2000, 2000, n)
+        o[:, ax] = val + rng.uniform(-0.7, 0.7, n)
+        d = rng.normal(size=(n, 3))
+        d[: n // 4, ax] *= 1e-5  # grazing
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        oo.append(o), dd.append(d.astype(np.float32))
+    oo, dd = np.concatenate(oo), np.concatenate(dd)
+    for gen in (scenes.cornell8, scenes.lattice):
+        p = Pair(*gen())
+        assert_raycast_equal(p.gpu.raycast(oo, dd), p.cpu.raycast(oo, dd))
+        for sampling in (0, 1):
+            opts = va.make_opts(seed=11, sampling=sampling)
+            rad, st = p.gpu.radiance(oo[::8], dd[::8], opts)
+            rrad, rst = p.cpu.radiance(oo[::8], dd[::8], opts)
+            assert np.all(same_f32(rad, rrad)) and st["rays_secondary"] == rst["rays_secondary"]
+        p.close()
+
+
 @pytest.mark.parametrize("ntris,leaf", [(1, 4), (3, 4), (5, 1), (8, 2), (8, 8), (200, 1), (200, 7), (200, 31)])
 def test_tiny_scenes_and_leaf_sizes(ntris, leaf):
     pos, nrm, uv = scenes.lattice() if ntris > 8 else scenes.cornell8()

@@ -342,7 +342,8 @@ __device__ __forceinline__ void tri_shading_normal(const SceneDev &sc, int slot,
 // decide, with a margin far above every rounding error involved (2^-20 relative against 2^-24 float
 // and 2^-53 double steps), that the double-precision result cannot matter:
 //   miss   : B^2 < (C - R2) - tol                 =>  det < 0, the reference returns 0
-//   behind : B < 0 and C >= R2                    =>  det <= fl(B^2), both roots <= 1e-4 (for |B| < 1e11): returns 0
+//   behind : B < 0 and (C - R2) > tol             =>  det < B^2 although (B^2 - C) + R2 rounds at the magnitude
+//            of C (2^-53 C, ~0.3 for the wall spheres), so both roots are <= 1e-4 (|B| < 1e11): returns 0
 //   far    : B > limit and (C - R2) - limit (2B - limit) > tol  =>  det < (B - limit)^2 (1 - 2^-40),
 //            so the smaller root rounds to >= limit and the caller ignores it
 // Only lanes that pass none of them need the exact evaluation; a wave runs it if any lane does (the
@@ -356,7 +357,7 @@ __device__ __forceinline__ float sphere_hit(float ox, float oy, float oz, float 
     const float tol_m = kRel * (C + R2 + BB);
     const float tol_f = kRel * (C + R2 + BB + limit * (2.f * fabsf(B) + limit));
     const bool miss = BB < X - tol_m;
-    const bool behind = B < 0.f && B > -1e11f && C >= R2;
+    const bool behind = B < 0.f && B > -1e11f && X > tol_m;
     const bool far = B > limit * (1.f + kRel) && (X - limit * (2.f * B - limit)) > tol_f;
     const bool need = !(miss || behind || far);
     float th = 0.f;
@@ -1967,8 +1968,8 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             rng_store(pa, pid, P.rng);
             if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, 1.f);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_ntrig = 0;
+        if (threadIdx.x == 0) s_ntrig = 0;  // everybody read it before the barrier above
+        __syncthreads();                    // ... and the next item's atomics come after this one
         tally_add(tl, fl, run, depth0);
         id_append(qout, item % kSubQueues, alive, pid);
     }
