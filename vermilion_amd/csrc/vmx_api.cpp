@@ -303,7 +303,8 @@ int run_queue(vmx_scene *sc, float r2scale, QueueDev q[2], int cur, void *rad, D
 }
 
 struct Tuning {
-    uint32_t refill_min, refill_primary, shade_min, leaf_min, lds_entries, tail_threshold;
+    uint32_t refill_min, refill_primary, shade_min, leaf_min, tail_threshold;
+    uint32_t lds_entries, lds_primary, lds_bounce;  // LDS stack levels: fused kernels, camera-ray trace, bounce trace
 };
 
 Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
@@ -314,8 +315,14 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.refill_primary = o->reserved[3] ? o->reserved[3] : 64u;
     tn.shade_min = o->reserved[4] ? o->reserved[4] : 16u;
     tn.leaf_min = o->reserved[5] ? o->reserved[5] : 0xFFFFFFFFu;  // k_paths only: triangle-step vote (default: majority)
-    const uint32_t cap = o->reserved[6] ? o->reserved[6] : 10u;  // 11 x 512 B per wave: 28 waves/CU fit in 160 KiB
-    tn.lds_entries = std::min(sc->dev.stack_entries, cap);
+    // LDS stack levels per lane (+1 scratch level), 512 B per level and wave.  Measured on the Sponza
+    // stand-in: camera rays rarely go deep and gain from the 8th wave per SIMD that 8 levels leave
+    // room for (52.6 -> 50.6 ms); incoherent bounce rays go deeper and prefer 13 levels at 6 waves to
+    // spilling levels into HBM (61.8 -> 60 ms); the fused kernels keep 10 (7 waves).
+    const uint32_t cap = o->reserved[6];
+    tn.lds_entries = std::min(sc->dev.stack_entries, cap ? cap : 10u);
+    tn.lds_primary = std::min(sc->dev.stack_entries, cap ? cap : 8u);
+    tn.lds_bounce = std::min(sc->dev.stack_entries, cap ? cap : 13u);
     // bounce generations with fewer live paths than this finish in one fused launch (measured on the
     // Sponza stand-in: 512 K -> 16 M = 155.7 -> 152.9 ms fixed spp, 23.6 -> 20.8 ms with early stop)
     tn.tail_threshold = o->reserved[2] ? o->reserved[2] : (16u << 20);
@@ -325,11 +332,11 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
 constexpr uint32_t kPathsBlock = 256;
 
 // fills the stack fields of a WorkDev and makes sure the global overflow slab is large enough
-int bind_stack(vmx_scene *sc, const Tuning &tn, uint32_t grid, WorkDev &wk) {
-    wk.lds_entries = tn.lds_entries;
+int bind_stack(vmx_scene *sc, const Tuning &tn, uint32_t entries, uint32_t grid, WorkDev &wk) {
+    wk.lds_entries = entries;
     wk.leaf_min = tn.leaf_min;
     // + 1: k_trace_w keeps its bottom entry in LDS level 0
-    wk.overflow_entries = sc->dev.stack_entries + 1 > tn.lds_entries ? sc->dev.stack_entries + 1 - tn.lds_entries : 1u;
+    wk.overflow_entries = sc->dev.stack_entries + 1 > entries ? sc->dev.stack_entries + 1 - entries : 1u;
     const size_t waves = (size_t)grid * (kPathsBlock / 64);
     if (sc->ws.overflow_stack.ensure(waves * wk.overflow_entries * 64 * 8))
         return fail(VMX_ERR_NOMEM, "hipMalloc failed for the overflow stack");
@@ -337,10 +344,10 @@ int bind_stack(vmx_scene *sc, const Tuning &tn, uint32_t grid, WorkDev &wk) {
     return VMX_OK;
 }
 
-LaunchCfg paths_cfg(const vmx_scene *sc, const Tuning &tn, uint64_t items, int blocks_per_cu) {
+LaunchCfg paths_cfg(const vmx_scene *sc, uint32_t entries, uint64_t items, int blocks_per_cu) {
     LaunchCfg c;
     c.block = kPathsBlock;
-    c.lds_bytes = (kPathsBlock / 64) * (tn.lds_entries + 1) * 512;
+    c.lds_bytes = (kPathsBlock / 64) * (entries + 1) * 512;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     uint64_t grid = (uint64_t)sc->num_cus * (uint64_t)blocks_per_cu;
     const uint64_t need = (items + kPathsBlock - 1) / kPathsBlock;
@@ -394,8 +401,9 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
         wk.nsrc = kSubQueues;
         wk.refill_min = tn.refill_min, wk.shade_min = tn.shade_min;
         wk.qids = q[cur];
-        LaunchCfg cfg = paths_cfg(sc, tn, total, tail ? tail_blocks : trace_blocks);
-        rc = bind_stack(sc, tn, cfg.grid, wk);
+        const uint32_t entries = tail ? tn.lds_entries : tn.lds_bounce;
+        LaunchCfg cfg = paths_cfg(sc, entries, total, tail ? tail_blocks : trace_blocks);
+        rc = bind_stack(sc, tn, entries, cfg.grid, wk);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
         TimedLaunch tl{ws.events.get(), ws.events.get(), 1};
@@ -539,12 +547,13 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     QueueDev q[2];
     PathArrays pa{};
     IdQueue qi[2];
-    int tb = 1;
+    int tb = 1, tbb = 1;  // blocks per CU of the trace kernel: camera rays, bounce rays
     if (split_any) {
         rc = ensure_paths(sc, (size_t)n_pad_max * smax, pa, qi);
         if (rc) return rc;
-        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_entries + 1) * 512, count, &tb));
-        if (tb < 1) return fail(VMX_ERR_HIP, "trace kernel does not fit on a CU");
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_primary + 1) * 512, count, &tb));
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, &tbb));
+        if (tb < 1 || tbb < 1) return fail(VMX_ERR_HIP, "trace kernel does not fit on a CU");
     } else if (legacy) {
         rc = ensure_queues(sc, sub_cap, q);
         if (rc) return rc;
@@ -639,8 +648,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.band_items = wk.band_slots * S;
             wk.pixel_major = 1;
             wk.cam_inner = ws.cam_inner.p, wk.cam_tris = ws.cam_tris.p;
-            LaunchCfg cfg = paths_cfg(sc, tn, (uint64_t)n_pad * S, tb);
-            rc = bind_stack(sc, tn, cfg.grid, wk);
+            LaunchCfg cfg = paths_cfg(sc, tn.lds_primary, (uint64_t)n_pad * S, tb);
+            rc = bind_stack(sc, tn, tn.lds_primary, cfg.grid, wk);
             if (rc) return rc;
             HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
             LAUNCH_TRY(launch_raygen(fr, wk, px, pa, s));
@@ -666,8 +675,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;
             wk.band_items = wk.band_slots * S;
             wk.pixel_major = 1;
-            LaunchCfg cfg = paths_cfg(sc, tn, (uint64_t)n_pad * S, rb);
-            rc = bind_stack(sc, tn, cfg.grid, wk);
+            LaunchCfg cfg = paths_cfg(sc, tn.lds_entries, (uint64_t)n_pad * S, rb);
+            rc = bind_stack(sc, tn, tn.lds_entries, cfg.grid, wk);
             if (rc) return rc;
             HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
             HIP_TRY(hipEventRecord(tl.a, s));
@@ -683,7 +692,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         timed.push_back(tl);
         launches += 2;
         if (split) {
-            rc = run_ids(sc, fr, pa, qi, 0, ws.counters.p, count, tn, s, timed, launches, tb, rb);
+            rc = run_ids(sc, fr, pa, qi, 0, ws.counters.p, count, tn, s, timed, launches, tbb, rb);
             if (rc) return rc;
         } else if (!mega) {
             rc = run_queue(sc, fr.r2scale, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed, launches,
@@ -992,7 +1001,7 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     } else {
         rc = ensure_paths(sc, n, pa, qi);
         if (rc) return rc;
-        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, lds_paths, count, &tb));
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, &tb));
         HIP_TRY((hipError_t)query_paths_blocks_per_cu(kPathsBlock, lds_paths, count, &rb));
     }
     DevBuf<float> d_o, d_d;

@@ -45,7 +45,7 @@ def make_opts(seed=1, early_stop=True, sampling=L.VMX_SAMPLING_PARITY, rank=0, w
     o.reserved[3] = int(refill_min)    # k_paths: refill when this many lanes idle (0 -> 16)
     o.reserved[4] = int(shade_min)     # k_paths: shade when this many lanes finished (0 -> 16)
     o.reserved[5] = int(leaf_min)      # k_paths: triangle step when this many lanes sit at a leaf (0 -> 16)
-    o.reserved[6] = int(lds_entries)   # k_paths: stack levels kept in LDS (0 -> 16), deeper ones spill to HBM
+    o.reserved[6] = int(lds_entries)   # stack levels kept in LDS, all kernels (0 -> 8 camera / 13 bounce / 10 fused); deeper ones spill to HBM
     return o
 
 
