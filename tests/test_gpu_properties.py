@@ -129,3 +129,55 @@ def test_4k_frame_config5_geometry(sponza):
     sel = np.arange(0, 3840 * 2160, 1013)
     rtri, rt = O.OracleScene(*scenes.sponza260k()).trace(o[sel], d[sel])
     assert np.array_equal(tri[sel], rtri) and np.array_equal(bits(t[sel]), bits(rt))
+
+
+def test_config4_full_frame_256spp(sponza):
+    """BASELINE config 4 at full size and full spp (the bench frame): pass split, stripe sharding
+    and the early-stop bookkeeping at the size the oracle cannot reach"""
+    W, H, spp = 1920, 1080, 256
+    cam = sponza_cam(W, H, spp)
+    a, sa = sponza.render(cam, va.make_opts(seed=1, early_stop=False))
+    assert sa["samples"] == W * H * spp == sa["rays_primary"] and sa["passes"] == 1
+    assert np.all(a[:, :, 4] == float(spp)) and np.all(np.isfinite(a))
+    b, sb = sponza.render(cam, va.make_opts(seed=1, early_stop=False, max_paths=100 << 20))
+    assert sb["passes"] > 1 and np.array_equal(bits(a), bits(b)) and sb["rays_secondary"] == sa["rays_secondary"]
+    part, _ = sponza.render(cam, va.make_opts(seed=1, early_stop=False, rank=3, world=8, stripe_rows=16))
+    assert np.array_equal(bits(part), bits(a[va.local_row_indices(H, 16, 3, 8)]))
+    # early stop (reference behaviour): 17 samples before the rule can fire, then at least the first
+    # sample of each of the 3 following strata; black pixels take exactly those 20
+    e, se = sponza.render(cam, va.make_opts(seed=1, early_stop=True))
+    n = e[:, :, 4]
+    assert n.min() == 20.0 and n.max() <= spp and se["samples"] == int(n.astype(np.int64).sum())
+    assert np.all(n[e[:, :, :3].sum(-1) == 0] == 20.0)
+    e2, se2 = sponza.render(cam, va.make_opts(seed=1, early_stop=True, max_paths=8 << 20, pipeline=4))
+    assert np.array_equal(bits(e), bits(e2)) and se2["samples"] == se["samples"]
+    parts = [sponza.render(cam, va.make_opts(seed=1, early_stop=True, rank=r, world=2, stripe_rows=16))[0] for r in range(2)]
+    for r in range(2):
+        assert np.array_equal(bits(parts[r]), bits(e[va.local_row_indices(H, 16, r, 2)]))
+
+
+def test_config3_bunny_1024_128spp():
+    """BASELINE config 3 at full size: split wavefront, fused kernel and first-generation kernels agree"""
+    sc = va.Scene(*scenes.bunny70k())
+    c = scenes.SCENES["bunny70k"][1]()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 1024, 1024, 128)
+    a, sa = sc.render(cam, va.make_opts(seed=9, early_stop=False))
+    assert sa["samples"] == 1024 * 1024 * 128 and np.all(np.isfinite(a))
+    for kw in (dict(pipeline=1), dict(pipeline=2, max_paths=32 << 20)):
+        b, sb = sc.render(cam, va.make_opts(seed=9, early_stop=False, **kw))
+        assert np.array_equal(bits(a), bits(b)), kw
+        assert sb["rays_secondary"] == sa["rays_secondary"]
+    sc.close()
+
+
+def test_config5_stripes_of_the_4k_1024spp_frame(sponza):
+    """BASELINE config 5 (3840x2160, 1024 spp, 8 ranks): what one rank renders equals its rows of the
+    whole frame rendered on one GPU"""
+    W, H, spp = 3840, 2160, 1024
+    cam = sponza_cam(W, H, spp)
+    full, sf = sponza.render(cam, va.make_opts(seed=8, early_stop=False))
+    assert sf["samples"] == W * H * spp and sf["passes"] > 1
+    for r in (0, 6):
+        part, sp = sponza.render(cam, va.make_opts(seed=8, early_stop=False, rank=r, world=8, stripe_rows=16))
+        assert np.array_equal(bits(part), bits(full[va.local_row_indices(H, 16, r, 8)]))
+        assert sp["samples"] == part.shape[0] * W * spp
