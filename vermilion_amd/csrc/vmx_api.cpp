@@ -580,7 +580,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     if (split_any) {
         // camera-relative copies of the node and triangle records for this frame's origin
         const size_t n_inner = std::max<size_t>(sc->bvh.inner.size(), 1);
-        if (ws.cam_inner.ensure(n_inner * 64) || ws.cam_tris.ensure((size_t)sc->ntris * 64))
+        if (ws.cam_inner.ensure(n_inner * 64 * 8) || ws.cam_tris.ensure((size_t)sc->ntris * 64))
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the camera tables");
         LAUNCH_TRY(launch_camera_tables(sc->dev, (uint32_t)sc->bvh.inner.size(), fr.px, fr.py, fr.pz, ws.cam_inner.p,
                                         ws.cam_tris.p, s));
@@ -648,6 +648,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.band_items = wk.band_slots * S;
             wk.pixel_major = 1;
             wk.cam_inner = ws.cam_inner.p, wk.cam_tris = ws.cam_tris.p;
+            wk.cam_n_inner = (uint32_t)sc->bvh.inner.size();
             LaunchCfg cfg = paths_cfg(sc, tn.lds_primary, (uint64_t)n_pad * S, tb);
             rc = bind_stack(sc, tn, tn.lds_primary, cfg.grid, wk);
             if (rc) return rc;

@@ -61,7 +61,8 @@ struct WorkDev {
     QueueDev qin;     // first-generation kernels (96-byte path records)
     IdQueue qids;     // k_trace_q / k_shade / tail (path ids)
     // camera rays: per-frame origin-relative node / triangle tables (k_camera_tables)
-    const void *cam_inner;  // float4[n_inner * 4]
+    const void *cam_inner;  // float4[8 * n_inner * 4]: one copy per direction octant, octant 0 = plain (lo, hi)
+    uint32_t cam_n_inner;   // records per copy
     const void *cam_tris;   // float4[ntris * 4]
 };
 

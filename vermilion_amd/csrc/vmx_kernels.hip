@@ -1340,10 +1340,21 @@ __global__ void k_camera_tables(SceneDev sc, uint32_t n_inner, float ox, float o
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (i < n_inner) {
             const float4 q0 = inner[i * 4], q1 = inner[i * 4 + 1], q2 = inner[i * 4 + 2], q3 = inner[i * 4 + 3];
-            cam_inner[i * 4] = make_float4(q0.x - ox, q0.y - oy, q0.z - oz, q0.w - ox);
-            cam_inner[i * 4 + 1] = make_float4(q1.x - oy, q1.y - oz, q1.z - ox, q1.w - oy);
-            cam_inner[i * 4 + 2] = make_float4(q2.x - oz, q2.y - ox, q2.z - oy, q2.w - oz);
-            cam_inner[i * 4 + 3] = q3;
+            // (lo - o), (hi - o) of both children, then one copy per direction octant (bit a: 1/d_a < 0)
+            // with each axis' near plane first: for a finite non-NaN reciprocal, min(lo*inv, hi*inv) is
+            // the product with lo when inv >= 0 and with hi otherwise (rounding is monotonic), so a wave
+            // whose rays share the octant needs 6 multiplies and one max3/min3 per box, no min/max pairs.
+            // Octant 0 is the plain (lo, hi) layout that the per-lane path reads.
+            const float l0x = q0.x - ox, l0y = q0.y - oy, l0z = q0.z - oz, h0x = q0.w - ox, h0y = q1.x - oy, h0z = q1.y - oz;
+            const float l1x = q1.z - ox, l1y = q1.w - oy, l1z = q2.x - oz, h1x = q2.y - ox, h1y = q2.z - oy, h1z = q2.w - oz;
+            for (uint32_t o = 0; o < 8; ++o) {
+                const bool sx = o & 1u, sy = o & 2u, sz = o & 4u;
+                float4 *rec = cam_inner + ((size_t)o * n_inner + i) * 4;
+                rec[0] = make_float4(sx ? h0x : l0x, sy ? h0y : l0y, sz ? h0z : l0z, sx ? l0x : h0x);
+                rec[1] = make_float4(sy ? l0y : h0y, sz ? l0z : h0z, sx ? h1x : l1x, sy ? h1y : l1y);
+                rec[2] = make_float4(sz ? h1z : l1z, sx ? l1x : h1x, sy ? l1y : h1y, sz ? l1z : h1z);
+                rec[3] = q3;
+            }
         } else {
             const uint32_t t = i - n_inner;
             const float4 a = tris[t * 3], b = tris[t * 3 + 1], c = tris[t * 3 + 2];
@@ -1687,6 +1698,9 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     float ix = 0.f, iy = 0.f, iz = 0.f, best = 0.f;
     int slot = -1, sp = 0;
     uint32_t cur = kIdle, pid = 0;
+    // camera rays: direction octant of the wave's rays if they all share it (else 8): selects the
+    // per-octant copy of the node table (k_camera_tables) for wave-uniform steps
+    uint32_t wave_octant = 8;
     stk[0] = make_uint2(kBottom, 0xFF800000u);  // bottom entry; pushes start at level 1, so it stays
 
     // One traversal step of every active lane.  The NaN-exact box form runs only while one of the
@@ -1744,11 +1758,22 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                 // and the products take the record straight from SGPRs
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                 typedef const __attribute__((address_space(4))) f32x4 *scalar_ptr;
-                const scalar_ptr rec = (scalar_ptr)(uintptr_t)(inner + (size_t)cur0 * 4);
-                const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                box_net(r0.x * ix, r0.y * iy, r0.z * iz, r0.w * ix, r1.x * iy, r1.y * iz, tn0, tf0);
-                box_net(r1.z * ix, r1.w * iy, r2.x * iz, r2.y * ix, r2.z * iy, r2.w * iz, tn1, tf1);
-                lref = __float_as_uint(r3.x), rref = __float_as_uint(r3.y);
+                if (wave_octant < 8) {
+                    // near planes first in this octant's copy: no min/max pairs
+                    const scalar_ptr rec = (scalar_ptr)(uintptr_t)(inner + ((size_t)wave_octant * wk.cam_n_inner + cur0) * 4);
+                    const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                    tn0 = vmax3(r0.x * ix, r0.y * iy, r0.z * iz);
+                    tf0 = vmin3(r0.w * ix, r1.x * iy, r1.y * iz);
+                    tn1 = vmax3(r1.z * ix, r1.w * iy, r2.x * iz);
+                    tf1 = vmin3(r2.y * ix, r2.z * iy, r2.w * iz);
+                    lref = __float_as_uint(r3.x), rref = __float_as_uint(r3.y);
+                } else {
+                    const scalar_ptr rec = (scalar_ptr)(uintptr_t)(inner + (size_t)cur0 * 4);
+                    const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                    box_net(r0.x * ix, r0.y * iy, r0.z * iz, r0.w * ix, r1.x * iy, r1.y * iz, tn0, tf0);
+                    box_net(r1.z * ix, r1.w * iy, r2.x * iz, r2.y * ix, r2.z * iy, r2.w * iz, tn1, tf1);
+                    lref = __float_as_uint(r3.x), rref = __float_as_uint(r3.y);
+                }
             } else {
                 const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2];
                 const float2 q3 = ((const float2 *)inner)[cur * 8 + 6];
@@ -1861,6 +1886,12 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         }
         const unsigned long long active = __builtin_amdgcn_ballot_w64(cur != kIdle);
         if (active == 0) break;
+        if (SRC == 0) {
+            const uint32_t oct = (__float_as_uint(ix) >> 31) | ((__float_as_uint(iy) >> 31) << 1) |
+                                 ((__float_as_uint(iz) >> 31) << 2);
+            const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)__ffsll((long long)active) - 1);
+            wave_octant = __builtin_amdgcn_ballot_w64(cur != kIdle && oct != o0) == 0 ? o0 : 8u;
+        }
         if (__builtin_amdgcn_ballot_w64(exact && cur != kIdle) != 0) {
 #pragma unroll 1
             for (int act = 0; act < 8; ++act) step(std::true_type{});
