@@ -1372,9 +1372,9 @@ __global__ void k_camera_tables(SceneDev sc, uint32_t n_inner, float ox, float o
 }
 
 // ---------------------------------------------------------------------------
-// k_raygen — camera rays of one pass (pathtracer.cpp:251-280): ray of path
-// pid = j * n_pad + slot into rayA/rayB (depth 0).  Slots whose sample index is
-// past the pixel's last sample get depth = ~0 and are skipped downstream.
+// k_raygen — camera rays of one pass (pathtracer.cpp:251-280), written to rayA[pid] as
+// (direction, depth flag): all camera rays share the frame's origin, so 16 bytes per ray suffice.
+// Slots whose sample index is past the pixel's last sample get depth = ~0 and are skipped downstream.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_raygen(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
@@ -1392,8 +1392,8 @@ k_raygen(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
             depth = 0;
         }
-        ((float4 *)pa.rayA)[pid] = make_float4(fr.px, fr.py, fr.pz, dx);
-        ((float4 *)pa.rayB)[pid] = make_float4(dy, dz, __uint_as_float(depth), 0.f);
+        // camera rays share the origin (FrameDev): one 16-byte record (direction, depth flag) in rayA
+        ((float4 *)pa.rayA)[pid] = make_float4(dx, dy, dz, __uint_as_float(depth));
     }
 }
 
@@ -1482,9 +1482,16 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                         pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
                     }
                     if (valid) {
-                        const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
-                        ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
-                        const uint32_t depth = __float_as_uint(b.z);
+                        uint32_t depth;
+                        if (SRC == 0) {  // camera ray: (direction, depth flag), origin from the frame
+                            const float4 a = ((const float4 *)pa.rayA)[pid];
+                            ox = fr.px, oy = fr.py, oz = fr.pz, dx = a.x, dy = a.y, dz = a.z;
+                            depth = __float_as_uint(a.w);
+                        } else {
+                            const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
+                            ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
+                            depth = __float_as_uint(b.z);
+                        }
                         valid = depth != 0xFFFFFFFFu;  // k_raygen marks sample slots past the pixel's last sample
                         counted = (depth == 0u) || finite3(dx, dy, dz);
                     }
@@ -1869,9 +1876,15 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                         pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
                     }
                     if (valid) {
-                        const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
-                        ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
-                        valid = __float_as_uint(b.z) != 0xFFFFFFFFu;  // sample slot past the pixel's last sample
+                        if (SRC == 0) {  // camera ray: (direction, depth flag), origin from the frame
+                            const float4 a = ((const float4 *)pa.rayA)[pid];
+                            ox = fr.px, oy = fr.py, oz = fr.pz, dx = a.x, dy = a.y, dz = a.z;
+                            valid = __float_as_uint(a.w) != 0xFFFFFFFFu;  // sample slot past the pixel's last sample
+                        } else {
+                            const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
+                            ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
+                            valid = __float_as_uint(b.z) != 0xFFFFFFFFu;
+                        }
                     }
                     if (valid) {
                         ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // Ray.h:10
@@ -1943,7 +1956,8 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             run = j < wk.samples && s_idx < wk.n_pad && primary_item(fr, wk, px, j, s_idx, pid2, pixel, k);
             if (run) {
                 // the ray comes from k_raygen; the stream is re-keyed and its two jitter draws skipped
-                ray_load(pa, pid, P);
+                const float4 a = ((const float4 *)pa.rayA)[pid];
+                P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz, P.dx = a.x, P.dy = a.y, P.dz = a.z, P.depth = 0;
                 rng_init(P.rng, fr.seed, pixel, k);
                 (void)rng_next(P.rng);
                 (void)rng_next(P.rng);
