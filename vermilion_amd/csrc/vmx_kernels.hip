@@ -1091,6 +1091,12 @@ __global__ void __launch_bounds__(256)
 k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, float4 *__restrict__ rad,
         PathArrays pa, DevCounters *ctr) {
     extern __shared__ uint2 lds_stack[];
+    __shared__ float4 s_geom[kLdsSpheres];  // spheres' (centre, rad*rad): read by every RayCast
+    if (threadIdx.x < min(sc.nspheres, kLdsSpheres)) {
+        const SphereDev &q = sc.spheres[threadIdx.x];
+        s_geom[threadIdx.x] = make_float4(q.cx, q.cy, q.cz, q.rad2);
+    }
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // the first lds_entries stack levels live in LDS, deeper ones (rare) in a per-wave global slab
     const int lds_entries = (int)wk.lds_entries;
@@ -1141,7 +1147,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                 if (shaded) {
                     depth0 = P.depth == 0 ? 1u : 0u;
                     CastResult c;
-                    cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, best, slot, c);
+                    cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, best, slot, c, s_geom);
                     fl.was_ray = is_ray;
                     alive = path_shade<TEX>(sc, fr.r2scale, P, c, fl);
                     if (!alive) {
