@@ -61,7 +61,7 @@ def main():
                       "MI355X_MICROARCH.md 'HBM'); WRITE_SIZE as read; separate --pmc passes; KB -> bytes x1024",
         "trace_kernel_hbm_bytes_per_launch": int(fetch + write),
         "algorithmic_bytes_per_launch": alg,
-        "expected_stream_bytes": f"32-B ray read + 8-B hit write per ray = {rays * 40 / 1e9:.1f} GB",
+        "expected_stream_bytes": f"16-B camera-ray read + 8-B hit write per ray = {rays * 24 / 1e9:.1f} GB",
         "l2_hit_rate": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
         "waves_per_launch": c["SQ_WAVES"],
         "valu_insts_per_launch": valu,
