@@ -137,6 +137,24 @@ def test_frame_bit_exact(pair, early_stop, sampling):
         assert st["samples_discarded"] == 0  # speculation only happens under early stop
 
 
+@pytest.mark.parametrize("spp", [24, 36, 64, 100, 256])
+def test_early_stop_frames_first_pass_carries_the_next_strata(spp):
+    """spp large enough that the first early-stop pass also carries the first samples of the
+    following strata (kernels: sample_index, FrameDev::lead): frames, sample counts and the pixels'
+    sample-count pattern equal the oracle's sequential loop, in every pipeline form"""
+    for gen, camf in (scenes.SCENES["cornell8"], scenes.SCENES["lattice"]):
+        p = Pair(*gen())
+        c = camf()
+        cam = va.make_camera(c["position"], c["rotation_deg"], 96, 64, spp, back_size=(3.6, 2.4))
+        for sampling in (0, 1):
+            ref, rst = p.cpu.render(cam, va.make_opts(seed=17, early_stop=True, sampling=sampling))
+            for kw in ({}, {"pipeline": 1}, {"pipeline": 2}, {"pipeline": 4}, {"max_paths": 50000}):
+                img, st = p.gpu.render(cam, va.make_opts(seed=17, early_stop=True, sampling=sampling, **kw))
+                assert np.array_equal(bits(img), bits(ref)), (spp, sampling, kw)
+                assert st["samples"] == rst["samples"] == int(ref[:, :, 4].astype(np.int64).sum())
+        p.close()
+
+
 @pytest.mark.parametrize("name", ["cornell8", "lattice"])
 def test_against_committed_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))

@@ -523,7 +523,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     uint32_t smax = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
     if (opts->samples_per_batch) smax = opts->samples_per_batch;
     smax = std::min(smax, fr.kmax);
-    if (fr.early_stop) smax = std::min(smax, fr.nmin + 1);  // larger groups are never issued under early stop
+    // under early stop no group is larger than the first one: nmin + 1 samples plus the first samples of the following strata
+    if (fr.early_stop) smax = std::min(smax, fr.nmin + 1 + (fr.quarter ? fr.kmax / fr.quarter - 1u : 0u));
     if (!fr.early_stop && !opts->samples_per_batch) {
         const uint32_t npass = (fr.kmax + smax - 1) / smax;
         smax = (fr.kmax + npass - 1) / npass;
@@ -601,9 +602,18 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         if (fr.early_stop) {
             // no sample can trigger the early-stop rule before n = nmin+1 (pathtracer.cpp:292):
             // up to there whole groups of samples are issued without speculation, after that one at a time
+            fr.lead = 0;
             if (n_uniform < fr.nmin + 1 && n_uniform < fr.kmax) {
                 S = std::min({fr.nmin + 1 - n_uniform, smax, fr.kmax - n_uniform});
                 n_uniform += S;
+                // Most pixels stop on the first test (sample nmin) and then on the first sample of every
+                // following stratum: when the whole group fits in one pass, those first samples ride
+                // along in it (sample_index / k_resolve), which saves a pass (measured 20.0 -> 17.5 ms)
+                const uint32_t strata_after = fr.quarter ? fr.kmax / fr.quarter - 1u : 0u;
+                if (S == fr.nmin + 1 && S <= fr.quarter && strata_after > 0 && S + strata_after <= smax) {
+                    fr.lead = S;
+                    S += strata_after;
+                }
             } else {
                 // Past that point a pixel may stop after any sample.  While most pixels are still
                 // active one sample per pass is issued (nothing speculative); once the active set is

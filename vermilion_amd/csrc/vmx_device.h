@@ -94,6 +94,8 @@ struct FrameDev {
     uint32_t kmax;                // 4*quarter
     uint32_t nmin;                // floor(sqrt(spp)): early stop needs n > sqrt(spp)
     uint32_t early_stop;
+    uint32_t lead;                // per pass: > 0 in the first early-stop pass — paths j < lead are samples j,
+                                  // paths j >= lead the first samples of the following strata (sample_index)
     float r2scale;                // 10 (parity) or 1 (corrected)
     uint32_t local_rows;          // rows owned by this rank
     uint32_t stripe_rows, rank, world;

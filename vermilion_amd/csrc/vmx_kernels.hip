@@ -814,6 +814,9 @@ __device__ __forceinline__ uint32_t path_id(const WorkDev &wk, uint32_t j, uint3
 constexpr uint32_t kCursorStrided = 0x80000000u;
 __device__ __forceinline__ uint32_t sample_index(const FrameDev &fr, const PixelStateDev &px, uint32_t lp,
                                                  uint32_t j) {
+    // first pass of an early-stop frame: the samples before the rule can fire (j < lead), and already
+    // the first samples of the following strata, for the many pixels that stop on the first test
+    if (fr.lead != 0 && j >= fr.lead) return (j - fr.lead + 1u) * fr.quarter;
     const uint32_t c = px.cursor[lp];
     return (c & ~kCursorStrided) + j * ((c & kCursorStrided) ? fr.quarter : 1u);
 }
@@ -2091,7 +2094,8 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
 #pragma unroll
             for (uint32_t i = 0; i < kChunk; ++i) {
                 const uint32_t j = j0 + i;
-                const uint32_t k = cursor + j * stride;
+                const bool lead_tail = fr.lead != 0 && j >= fr.lead;  // a following stratum's first sample
+                const uint32_t k = lead_tail ? (j - fr.lead + 1u) * fr.quarter : cursor + j * stride;
                 if (stop || j >= samples || k >= fr.kmax) {
                     stop = true;
                     continue;
@@ -2112,16 +2116,27 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
                 }
                 // number of this pass's paths that come after sample j
                 uint32_t later = samples - 1u - j;
-                if (cursor + (samples - 1u) * stride >= fr.kmax) later = (fr.kmax - 1u - k) / stride;
+                if (fr.lead != 0) {
+                    const uint32_t strata_after = fr.kmax / fr.quarter - 1u;
+                    const uint32_t valid = fr.lead + (samples - fr.lead < strata_after ? samples - fr.lead : strata_after);
+                    later = valid - 1u - j;
+                } else if (cursor + (samples - 1u) * stride >= fr.kmax) {
+                    later = (fr.kmax - 1u - k) / stride;
+                }
+                const bool strided_now = strided || lead_tail;
+                const bool lead_last = fr.lead != 0 && j + 1u == fr.lead;  // the first sample the rule can stop
                 if (early) {
                     brk = 1;
                     next = (k / fr.quarter + 1u) * fr.quarter;  // break the innermost loop only
                     flag = true;
-                    if (!strided) {  // the rest of this pass's consecutive samples is not taken
+                    // consecutive samples that follow in this pass are not taken — except that a lead
+                    // pass goes on with the next strata's first samples, which are exactly what is due
+                    if (!strided_now && !lead_last) {
                         disc = later;
                         stop = true;
                     }
-                } else if (strided) {  // this stratum goes on with sample k + 1; later strata were not due yet
+                } else if (strided_now || lead_last) {
+                    // this stratum goes on with sample k + 1; the later strata were not due yet
                     next = k + 1u;
                     flag = false;
                     disc = later;
