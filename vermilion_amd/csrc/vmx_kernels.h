@@ -47,7 +47,7 @@ struct WorkDev {
     uint32_t nsrc;              // 8 image bands (primary) or kSubQueues (queue)
     uint32_t refill_min;        // refill when this many lanes of a wave are idle
     uint32_t shade_min;         // shade when this many lanes have finished traversal
-    uint32_t leaf_min;          // run the triangle step when this many lanes sit at a leaf
+    uint32_t leaf_min;          // k_paths: run the triangle step when this many lanes sit at a leaf
     uint32_t lds_entries;       // stack levels kept in LDS
     uint32_t overflow_entries;  // deeper levels, in the global slab below (64 lanes x 8 B each)
     void *overflow_stack;       // uint2[waves][overflow_entries][64]
@@ -101,7 +101,7 @@ int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pixe
                  void *rad, DevCounters *counters, bool count, bool from_queue, bool loop_to_end, LaunchCfg cfg,
                  void *stream);
 int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks);
-// split wavefront: lean persistent trace kernel (vote-scheduled traversal, per-lane refill) ...
+// split wavefront: persistent trace kernel (per-lane refill) ...
 int launch_camera_tables(const SceneDev &sc, uint32_t n_inner, float ox, float oy, float oz, void *cam_inner,
                          void *cam_tris, void *stream);
 int launch_raygen(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);

@@ -1407,11 +1407,12 @@ k_raygen(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
 }
 
 // ---------------------------------------------------------------------------
-// k_trace_q — the lean persistent traversal kernel of the split wavefront
-// (BVH::getIntersection only, bvh.cpp:47-145).  Lane state is one ray; lanes
-// refill themselves from the work source; the wave votes between the inner
-// step and the triangle step.  Writes hit[pid] = (t, leaf slot).
-//   SRC 0: primary rays, generated from (pixel, sample) — origin is uniform
+// k_trace_q — the first form of the split wavefront's persistent traversal kernel
+// (BVH::getIntersection only, bvh.cpp:47-145), now the instrumented build (visit
+// counters, vmx_opts.collect_counters) and an A/B reference for k_trace_w below.
+// Lane state is one ray; lanes refill themselves from the work source.
+// Writes hit[pid] = (t, leaf slot).
+//   SRC 0: camera rays written by k_raygen (direction in rayA, the frame's origin)
 //   SRC 1: bounce rays of the queued path ids, read from rayA/rayB
 // ---------------------------------------------------------------------------
 template <bool COUNT, int SRC>
@@ -1648,7 +1649,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 }
 
 // ---------------------------------------------------------------------------
-// k_trace_w — k_trace_q's production form (no counters, no vote), written for the
+// k_trace_w — k_trace_q's production form (no counters), written for the
 // limit the SQ counters show this loop runs at: instruction delivery.  One
 // traversal step of the first form executed ~62 VALU + ~47 SALU + ~12 branch
 // instructions, and the instruction cache two CUs share was busy ~100 % of the
