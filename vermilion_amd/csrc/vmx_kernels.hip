@@ -482,7 +482,7 @@ __device__ __forceinline__ float4 tex_sample(const SceneDev &sc, float u, float 
 
 // The loop body is split where the cosine-lobe branch needs cos/sin of r1 (double precision, a few
 // hundred instructions): only ~10 % of the paths get there (the others end, or bounce off the
-// mirror lobe), so k_shade gathers those angles of a whole block and evaluates them in full waves.
+// mirror lobe) — a wave in which no lane gets there skips them.
 struct ShadeMid {
     float sx, sy, sz;  // origin of the next ray
     float r2s, q;      // sqrt(r2), sqrt(1 - r2)
@@ -1941,11 +1941,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
         DevCounters *ctr) {
     const float2 *__restrict__ hits = (const float2 *)pa.hit;
     float4 *__restrict__ rad = (float4 *)pa.rad;
-    __shared__ double s_angle[256];
-    __shared__ float s_cs[256], s_sn[256];
-    __shared__ unsigned int s_ntrig;
     __shared__ float4 s_geom[kLdsSpheres];
-    if (threadIdx.x == 0) s_ntrig = 0;
     if (threadIdx.x < min(sc.nspheres, kLdsSpheres)) {
         const SphereDev &q = sc.spheres[threadIdx.x];
         s_geom[threadIdx.x] = make_float4(q.cx, q.cy, q.cz, q.rad2);
@@ -1998,33 +1994,15 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
             rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
         }
-        // gather the block's angles, evaluate cos/sin in full waves, hand the values back
-        const bool trig = st == kPathNeedsTrig;
-        uint32_t tslot = 0;
-        {
-            const unsigned long long m = __ballot(trig);
-            uint32_t base = 0;
-            if (m != 0 && lane_index() == 0) base = atomicAdd(&s_ntrig, (uint32_t)__popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            tslot = base + (uint32_t)__popcll(m & ((1ull << lane_index()) - 1ull));
-            if (trig) s_angle[tslot] = mid.angle;
-        }
-        __syncthreads();
-        if (threadIdx.x < s_ntrig) {
-            const double a = s_angle[threadIdx.x];
-            s_cs[threadIdx.x] = (float)cos(a);
-            s_sn[threadIdx.x] = (float)sin(a);
-        }
-        __syncthreads();
         bool alive = st == kPathNextRay;
-        if (trig) alive = path_shade_end(P, c, fl, mid, s_cs[tslot], s_sn[tslot]);
+        // (gathering the block's ~10 % of angles in LDS to evaluate cos/sin in full waves was measured:
+        // the three barriers it needs cost what it saves)
+        if (st == kPathNeedsTrig) alive = path_shade_end(P, c, fl, mid, (float)cos(mid.angle), (float)sin(mid.angle));
         if (alive) {
             ray_store(pa, pid, P);
             rng_store(pa, pid, P.rng);
             if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, 1.f);
         }
-        if (threadIdx.x == 0) s_ntrig = 0;  // everybody read it before the barrier above
-        __syncthreads();                    // ... and the next item's atomics come after this one
         tally_add(tl, fl, run, depth0);
         id_append(qout, item % kSubQueues, alive, pid);
     }
