@@ -107,7 +107,7 @@ struct Workspace {
     DevBuf<unsigned int> queue_counts;  // 2 * kSubQueues * 32
     DevBuf<unsigned int> heads;         // kSubQueues * 32 reservation heads of k_paths
     DevBuf<unsigned char> overflow_stack;  // k_paths: stack levels beyond the LDS part
-    DevBuf<unsigned char> rayA, rayB, rngA, rngB, hit, thr;  // split wavefront: per-path state
+    DevBuf<unsigned char> rayA, state, hit, thr;  // split wavefront: per-path state
     DevBuf<unsigned int> ids[2], id_counts;             // split wavefront: live path ids
     DevBuf<unsigned char> cam_inner, cam_tris;          // per-frame camera-relative scene tables
     DevBuf<unsigned char> rad;          // float4 per path of a pass
@@ -120,7 +120,7 @@ struct Workspace {
     EventPool events;
     void release() {
         queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), heads.release(), overflow_stack.release();
-        rayA.release(), rayB.release(), rngA.release(), rngB.release(), hit.release(), thr.release();
+        rayA.release(), state.release(), hit.release(), thr.release();
         ids[0].release(), ids[1].release(), id_counts.release(), cam_inner.release(), cam_tris.release();
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
@@ -360,12 +360,12 @@ LaunchCfg paths_cfg(const vmx_scene *sc, uint32_t entries, uint64_t items, int b
 int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[2]) {
     Workspace &ws = sc->ws;
     const uint32_t sub_cap = (uint32_t)(nslots / kSubQueues + 1024);
-    if (ws.rayA.ensure(nslots * 16) || ws.rayB.ensure(nslots * 16) || ws.rngA.ensure(nslots * 16) ||
-        ws.rngB.ensure(nslots * 16) || ws.hit.ensure(nslots * 8) || ws.rad.ensure(nslots * 16) ||
+    if (ws.rayA.ensure(nslots * 16) || ws.state.ensure(nslots * 64) || ws.hit.ensure(nslots * 8) ||
+        ws.rad.ensure(nslots * 16) ||
         ws.ids[0].ensure((size_t)sub_cap * kSubQueues) || ws.ids[1].ensure((size_t)sub_cap * kSubQueues) ||
         ws.id_counts.ensure(2 * kSubQueues * 32) || ws.heads.ensure(kSubQueues * 32) || ws.counters.ensure(1))
         return fail(VMX_ERR_NOMEM, "hipMalloc failed for the path arrays");
-    pa.rayA = ws.rayA.p, pa.rayB = ws.rayB.p, pa.rngA = ws.rngA.p, pa.rngB = ws.rngB.p;
+    pa.rayA = ws.rayA.p, pa.state = ws.state.p;
     pa.hit = ws.hit.p, pa.rad = ws.rad.p;
     pa.thr = nullptr;
     if (sc->dev.tex) {

@@ -24,10 +24,11 @@ struct PixelStateDev {
 // Per-pass path state, one slot per path id `pid` = sample_plane * n_pad + slot (fixed for the
 // pass: compaction between bounces moves 4-byte ids, never the state).
 struct PathArrays {
-    void *rayA;   // float4 (o.x, o.y, o.z, d.x)            bounce rays only
-    void *rayB;   // float4 (d.y, d.z, bits(depth), 0)
-    void *rngA;   // float4 = xoshiro s0, s1
-    void *rngB;   // float4 = xoshiro s2, s3
+    void *rayA;   // camera rays: float4 (d.x, d.y, d.z, bits(depth flag)), read densely by path id
+    // paths past their first hit: one 64-byte record per path id — (o.xyz, d.x) (d.yz, bits(depth), 0)
+    // (xoshiro s0, s1) (s2, s3).  Few paths live on (16 % after the first hit with the reference's
+    // sampling), so their readers touch scattered ids: one line per path instead of four.
+    void *state;
     void *hit;    // float2 (t of the BVH query, bits(leaf slot or -1))
     void *rad;    // float4 accumColour, updated in place; final when the path ends
     void *thr;    // float4 accumRadiance (rgb); only with a bound texture (else it stays 1,1,1)

@@ -753,24 +753,24 @@ __device__ __forceinline__ uint32_t global_pixel(const FrameDev &fr, uint32_t lp
 
 // ---- path state in per-pass arrays (split wavefront) ---------------------------------------
 __device__ __forceinline__ void rng_store(const PathArrays &pa, uint32_t pid, const Rng &r) {
-    ((float4 *)pa.rngA)[pid] = make_float4(__uint_as_float((uint32_t)r.s0), __uint_as_float((uint32_t)(r.s0 >> 32)),
+    ((float4 *)pa.state)[(size_t)pid * 4 + 2] = make_float4(__uint_as_float((uint32_t)r.s0), __uint_as_float((uint32_t)(r.s0 >> 32)),
                                            __uint_as_float((uint32_t)r.s1), __uint_as_float((uint32_t)(r.s1 >> 32)));
-    ((float4 *)pa.rngB)[pid] = make_float4(__uint_as_float((uint32_t)r.s2), __uint_as_float((uint32_t)(r.s2 >> 32)),
+    ((float4 *)pa.state)[(size_t)pid * 4 + 3] = make_float4(__uint_as_float((uint32_t)r.s2), __uint_as_float((uint32_t)(r.s2 >> 32)),
                                            __uint_as_float((uint32_t)r.s3), __uint_as_float((uint32_t)(r.s3 >> 32)));
 }
 __device__ __forceinline__ void rng_load(const PathArrays &pa, uint32_t pid, Rng &r) {
-    const float4 e = ((const float4 *)pa.rngA)[pid], f = ((const float4 *)pa.rngB)[pid];
+    const float4 e = ((const float4 *)pa.state)[(size_t)pid * 4 + 2], f = ((const float4 *)pa.state)[(size_t)pid * 4 + 3];
     r.s0 = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
     r.s1 = (uint64_t)__float_as_uint(e.z) | ((uint64_t)__float_as_uint(e.w) << 32);
     r.s2 = (uint64_t)__float_as_uint(f.x) | ((uint64_t)__float_as_uint(f.y) << 32);
     r.s3 = (uint64_t)__float_as_uint(f.z) | ((uint64_t)__float_as_uint(f.w) << 32);
 }
 __device__ __forceinline__ void ray_store(const PathArrays &pa, uint32_t pid, const Path &P) {
-    ((float4 *)pa.rayA)[pid] = make_float4(P.ox, P.oy, P.oz, P.dx);
-    ((float4 *)pa.rayB)[pid] = make_float4(P.dy, P.dz, __uint_as_float(P.depth), 0.f);
+    ((float4 *)pa.state)[(size_t)pid * 4] = make_float4(P.ox, P.oy, P.oz, P.dx);
+    ((float4 *)pa.state)[(size_t)pid * 4 + 1] = make_float4(P.dy, P.dz, __uint_as_float(P.depth), 0.f);
 }
 __device__ __forceinline__ void ray_load(const PathArrays &pa, uint32_t pid, Path &P) {
-    const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
+    const float4 a = ((const float4 *)pa.state)[(size_t)pid * 4], b = ((const float4 *)pa.state)[(size_t)pid * 4 + 1];
     P.ox = a.x, P.oy = a.y, P.oz = a.z, P.dx = a.w;
     P.dy = b.x, P.dz = b.y, P.depth = __float_as_uint(b.z);
 }
@@ -1498,7 +1498,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                             ox = fr.px, oy = fr.py, oz = fr.pz, dx = a.x, dy = a.y, dz = a.z;
                             depth = __float_as_uint(a.w);
                         } else {
-                            const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
+                            const float4 a = ((const float4 *)pa.state)[(size_t)pid * 4], b = ((const float4 *)pa.state)[(size_t)pid * 4 + 1];
                             ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
                             depth = __float_as_uint(b.z);
                         }
@@ -1891,7 +1891,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                             ox = fr.px, oy = fr.py, oz = fr.pz, dx = a.x, dy = a.y, dz = a.z;
                             valid = __float_as_uint(a.w) != 0xFFFFFFFFu;  // sample slot past the pixel's last sample
                         } else {
-                            const float4 a = ((const float4 *)pa.rayA)[pid], b = ((const float4 *)pa.rayB)[pid];
+                            const float4 a = ((const float4 *)pa.state)[(size_t)pid * 4], b = ((const float4 *)pa.state)[(size_t)pid * 4 + 1];
                             ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
                             valid = __float_as_uint(b.z) != 0xFFFFFFFFu;
                         }
