@@ -513,7 +513,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         return VMX_OK;
     }
 
-    // pass sizing — paths in flight per pass: up to 640 M path slots = 56 GB of per-path state (288 GB of HBM per
+    // pass sizing — paths in flight per pass: up to 640 M path slots = 67 GB of per-path state (288 GB of HBM per
     // GPU); large passes keep the small late-bounce launches few (16 M -> 640 M per pass: 1.8x on the
     // whole frame).  Fixed-spp passes are balanced: ceil(kmax / passes) samples each.
     // (the first-generation kernels move 96-byte records through two queues: 16 M paths there)
