@@ -178,6 +178,8 @@ int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32
 #define VMX_BVH_REFERENCE 0u /* BVH::build's topology (bvh.cpp:179-279): triangle-ID / tie parity        */
 #define VMX_BVH_SAH 1u       /* binned-SAH quality tree: same triangle tests and nearest
                                 distance, but exact-distance ties and `near > t` pruning follow ITS order */
+#define VMX_BVH_LBVH 2u      /* linear BVH built on the GPU (Morton sort, Karras hierarchy, bottom-up fit):
+                                milliseconds to build, for scenes that change per frame; same caveat as SAH */
 int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                         const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size, uint32_t builder,
                         int device, vmx_scene **out);

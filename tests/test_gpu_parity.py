@@ -456,14 +456,15 @@ def test_textured_paths_bit_exact_f2(channels, size):
 
 
 @pytest.mark.parametrize("name", ["lattice", "bunny70k", "sponza260k"])
-def test_quality_bvh_builder_f1(name):
-    """§8 f-1: the binned-SAH tree.  (1) the reference's traversal run over the SAME tree (oracle fed
+@pytest.mark.parametrize("builder", ["sah", "lbvh"])
+def test_quality_bvh_builder_f1(name, builder):
+    """§8 f-1: the binned-SAH tree (host) and the linear BVH built on the GPU.  (1) the reference's traversal run over the SAME tree (oracle fed
     the exported flat tree) agrees bit for bit; (2) against the reference-topology tree the nearest hit
     is the same triangle at the same distance except where two triangles are hit at the same t."""
     gen, camf = scenes.SCENES[name]
     pos, nrm, uv = gen()
     ref = va.Scene(pos, nrm, uv)
-    sah = va.Scene(pos, nrm, uv, builder=va._lib.VMX_BVH_SAH)
+    sah = va.Scene(pos, nrm, uv, builder=va._lib.VMX_BVH_SAH if builder == "sah" else va._lib.VMX_BVH_LBVH)
     tree = sah.bvh()
     d = sah.describe()
     assert d["n_nodes"] == len(tree["start"]) and sorted(tree["prim_order"].tolist()) == list(range(pos.shape[0]))
@@ -489,7 +490,7 @@ def test_quality_bvh_builder_f1(name):
         img, st = sah.render(cam, opts)
         oimg, ost = osc.render(cam, opts)
         assert np.array_equal(bits(img), bits(oimg))
-    if name == "sponza260k":
+    if name == "sponza260k" and builder == "sah":
         # the point of the builder: fewer node visits than the reference's median split
         _, _, rcnt = O.OracleScene(pos, nrm, uv).trace(o, dd, counters=True)
         assert cnt["inner_visits"] < 0.7 * rcnt["inner_visits"]

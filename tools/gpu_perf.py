@@ -15,7 +15,7 @@ def main():
     reps = int(sys.argv[6]) if len(sys.argv) > 6 else 2
     gen, camf = scenes.SCENES[name]
     pos, nrm, uv = gen()
-    sc = va.Scene(pos, nrm, uv, builder=int(os.environ.get("BUILDER", "0")))
+    sc = va.Scene(pos, nrm, uv, builder=int(os.environ.get("BUILDER", "0")))  # 0 reference, 1 SAH, 2 GPU LBVH
     print(name, sc.describe())
     c = camf()
     cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))

@@ -22,6 +22,7 @@ VMX_SAMPLING_PARITY = 0
 VMX_SAMPLING_CORRECTED = 1
 VMX_BVH_REFERENCE = 0
 VMX_BVH_SAH = 1
+VMX_BVH_LBVH = 2
 
 
 class Sphere(C.Structure):

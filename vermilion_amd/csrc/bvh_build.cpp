@@ -207,6 +207,13 @@ bool build_bvh(const float *pos, const float *nrm, const float *uv, uint32_t ntr
 }
 
 
+bool check_bvh_input(const float *pos, const float *nrm, uint32_t ntris, uint32_t &leaf_size, std::string &err) {
+    return check_input(pos, nrm, ntris, leaf_size, err);
+}
+bool flatten_bvh(const float *pos, const float *nrm, const float *uv, uint32_t ntris, HostBvh &out, std::string &err) {
+    return flatten(pos, nrm, uv, ntris, out, err);
+}
+
 // ---------------------------------------------------------------------------
 // Quality builder: binned surface-area heuristic, 16 bins per
 // axis, same flat layout.  NOT the reference's topology: the nearest hit is the

@@ -32,4 +32,13 @@ bool build_bvh(const float *pos, const float *nrm, const float *uv, uint32_t ntr
 bool build_bvh_sah(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                    uint32_t leaf_size, HostBvh &out, std::string &err);
 
+// linear BVH built on the GPU (Morton sort + Karras hierarchy + bottom-up fit, lbvh_build.hip), linearised on
+// the host into the same flat layout; not the reference's topology either
+bool build_bvh_lbvh(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
+                    int device, HostBvh &out, std::string &err);
+
+// shared by the builders: input validation; flat tree (start/nprims/right_offset/bbox/prim_order) -> device records
+bool check_bvh_input(const float *pos, const float *nrm, uint32_t ntris, uint32_t &leaf_size, std::string &err);
+bool flatten_bvh(const float *pos, const float *nrm, const float *uv, uint32_t ntris, HostBvh &out, std::string &err);
+
 }  // namespace vmx

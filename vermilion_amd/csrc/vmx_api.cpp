@@ -756,7 +756,7 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
                         const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size, uint32_t builder,
                         int device, vmx_scene **out) {
     if (!out) return fail(VMX_ERR_INVALID, "out is NULL");
-    if (builder > VMX_BVH_SAH) return fail(VMX_ERR_INVALID, "unknown BVH builder");
+    if (builder > VMX_BVH_LBVH) return fail(VMX_ERR_INVALID, "unknown BVH builder");
     *out = nullptr;
     if (!pos || !nrm || ntris == 0) return fail(VMX_ERR_INVALID, "scene needs positions, normals, ntris > 0");
     if (spheres == nullptr && nspheres != 0)
@@ -772,8 +772,9 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
     sc->ntris = ntris;
     sc->leaf_size = leaf_size ? leaf_size : 4;
     std::string err;
-    const bool built = builder == VMX_BVH_SAH ? build_bvh_sah(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err)
-                                              : build_bvh(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err);
+    const bool built = builder == VMX_BVH_SAH    ? build_bvh_sah(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err)
+                       : builder == VMX_BVH_LBVH ? build_bvh_lbvh(pos, nrm, uv, ntris, sc->leaf_size, device, sc->bvh, err)
+                                                 : build_bvh(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err);
     if (!built) {
         const int code = err.find("deeper") != std::string::npos ? VMX_ERR_DEPTH : VMX_ERR_INVALID;
         delete sc;
