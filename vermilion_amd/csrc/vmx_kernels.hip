@@ -348,10 +348,11 @@ __device__ __forceinline__ void tri_shading_normal(const SceneDev &sc, int slot,
 //            so the smaller root rounds to >= limit and the caller ignores it
 // Only lanes that pass none of them need the exact evaluation; a wave runs it if any lane does (the
 // 64 camera rays of a wave belong to one pixel and mostly agree).
-__device__ __forceinline__ float sphere_hit(float ox, float oy, float oz, float dx, float dy, float dz,
-                                            float4 geom /* centre, rad*rad */, float limit) {
-    const float opx = geom.x - ox, opy = geom.y - oy, opz = geom.z - oz;
-    const float B = dot3(opx, opy, opz, dx, dy, dz), C = dot3(opx, opy, opz, opx, opy, opz), R2 = geom.w;
+// (op = centre - origin and C = op.op are passed in: for camera rays they are the same for every path
+// of a frame and come precomputed, by the same float operations, from LDS)
+__device__ __forceinline__ float sphere_hit_op(float opx, float opy, float opz, float C, float R2, float dx, float dy,
+                                               float dz, float limit) {
+    const float B = dot3(opx, opy, opz, dx, dy, dz);
     const float X = C - R2, BB = B * B;
     constexpr float kRel = 9.5367431640625e-07f;  // 2^-20
     const float tol_m = kRel * (C + R2 + BB);
@@ -378,6 +379,11 @@ __device__ __forceinline__ float sphere_hit(float ox, float oy, float oz, float 
     }
     return th;
 }
+__device__ __forceinline__ float sphere_hit(float ox, float oy, float oz, float dx, float dy, float dz,
+                                            float4 geom /* centre, rad*rad */, float limit) {
+    const float opx = geom.x - ox, opy = geom.y - oy, opz = geom.z - oz;
+    return sphere_hit_op(opx, opy, opz, dot3(opx, opy, opz, opx, opy, opz), geom.w, dx, dy, dz, limit);
+}
 
 struct CastResult {
     float nearest;     // INFINITY on a miss
@@ -395,7 +401,7 @@ struct CastResult {
 constexpr uint32_t kLdsSpheres = 16;
 __device__ __forceinline__ void cast_finish(const SceneDev &sc, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float best, int slot, CastResult &r,
-                                            const float4 *geom = nullptr) {
+                                            const float4 *geom = nullptr, const float4 *cam_op = nullptr) {
     r.nearest = kInf;
     r.nx = r.ny = r.nz = 0.f;
     r.cr = r.cg = r.cb = 0.f;
@@ -418,7 +424,13 @@ __device__ __forceinline__ void cast_finish(const SceneDev &sc, float ox, float 
             const SphereDev &q = sc.spheres[i];
             g = make_float4(q.cx, q.cy, q.cz, q.rad2);
         }
-        const float th = sphere_hit(ox, oy, oz, dx, dy, dz, g, r.nearest);
+        float th;
+        if (cam_op != nullptr && i < kLdsSpheres) {  // (centre - camera, its squared length): camera rays only
+            const float4 q = cam_op[i];
+            th = sphere_hit_op(q.x, q.y, q.z, q.w, g.w, dx, dy, dz, r.nearest);
+        } else {
+            th = sphere_hit(ox, oy, oz, dx, dy, dz, g, r.nearest);
+        }
         if (th > 0.f && th < r.nearest) {
             const SphereDev s = sc.spheres[i];
             r.nearest = th;
@@ -1942,9 +1954,12 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
     const float2 *__restrict__ hits = (const float2 *)pa.hit;
     float4 *__restrict__ rad = (float4 *)pa.rad;
     __shared__ float4 s_geom[kLdsSpheres];
+    __shared__ float4 s_cam_op[kLdsSpheres];  // SRC 0: (centre - camera position, squared length), same for every path
     if (threadIdx.x < min(sc.nspheres, kLdsSpheres)) {
         const SphereDev &q = sc.spheres[threadIdx.x];
         s_geom[threadIdx.x] = make_float4(q.cx, q.cy, q.cz, q.rad2);
+        const float opx = q.cx - fr.px, opy = q.cy - fr.py, opz = q.cz - fr.pz;
+        s_cam_op[threadIdx.x] = make_float4(opx, opy, opz, dot3(opx, opy, opz, opx, opy, opz));
     }
     __syncthreads();
     Tally tl = {{0, 0}, {0, 0}, {0, 0}};
@@ -1990,7 +2005,8 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             depth0 = P.depth == 0 ? 1u : 0u;
             fl.was_ray = depth0 ? true : finite3(P.dx, P.dy, P.dz);
             const float2 h = hits[pid];
-            cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom);
+            cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom,
+                        SRC == 0 ? s_cam_op : nullptr);
             st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
             rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
         }
