@@ -1736,48 +1736,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     // wave's rays needs it.
     auto step = [&](auto exact_tag) {
         constexpr bool EXACT = decltype(exact_tag)::value;  // NaN-exact box form
-        if ((int)cur < 0) {
-            // ---- one triangle of the leaf (triangle.cpp:4-54); the ref itself carries the progress
-            float det, inv_det, u, v, dist;
-            if (SRC == 0) {
-                const uint32_t ti = (cur & kLeafStartMask) * 4;
-                const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
-                const float cd = ((const float *)tris)[ti * 4 + 12];
-                // a = (e1, e2.x)  b = (e2.yz, tvec.xy)  c = (tvec.z, qvec)  cd = dot(e2, qvec)
-                float pvx, pvy, pvz;
-                cross3(dx, dy, dz, a.w, b.x, b.y, pvx, pvy, pvz);
-                det = dot3(a.x, a.y, a.z, pvx, pvy, pvz);
-                inv_det = 1.0f / det;
-                u = dot3(b.z, b.w, c.x, pvx, pvy, pvz) * inv_det;
-                v = dot3(dx, dy, dz, c.y, c.z, c.w) * inv_det;
-                dist = cd * inv_det;
-            } else {
-                const uint32_t ti = (cur & kLeafStartMask) * 3;
-                const float4 a = tris[ti], b = tris[ti + 1];
-                const float e2z = ((const float *)tris)[ti * 4 + 8];
-                const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w;
-                float pvx, pvy, pvz;
-                cross3(dx, dy, dz, e2x, e2y, e2z, pvx, pvy, pvz);
-                det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
-                inv_det = 1.0f / det;
-                const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
-                u = dot3(tx, ty, tz, pvx, pvy, pvz) * inv_det;
-                float qx, qy, qz;
-                cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
-                v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
-                dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
-            }
-            const bool parallel = fabsf(det) <= 9.99999993922529e-09f;
-            const bool u_out = (u < 0.0f) || (u > 1.0f);
-            const bool v_out = (v < 0.0f) || (u + v > 1.0f);
-            const bool hit = !parallel && !u_out && !v_out && (dist > 0.0f);
-            if (hit && dist < best) {  // strict <: first tested wins ties (bvh.cpp:90)
-                best = dist;
-                slot = (int)(cur & kLeafStartMask);
-            }
-            // next triangle: start + 1, count - 1; after the last one the lane pops
-            cur = (((cur >> kLeafCountShift) & 31u) == 1u) ? kPop : cur + (1u - (1u << kLeafCountShift));
-        } else if (cur != kIdle) {
+        // inner references are the values below kPop; leaf references have bit 31; kPop/kBottom/kIdle lie between
+        if (cur < kPop) {
             // ---- inner node: both children boxes (bbox.cpp:70-83), nearer child first (bvh.cpp:103-132)
             float tn0, tf0, tn1, tf1;
             uint32_t lref, rref;
@@ -1836,6 +1796,47 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             const float near = go_right ? tn1 : tn0;
             // no child hit, or the child taken directly fails `near > t` (bvh.cpp:69): pop
             cur = (!(h0 || h1) || (near > best)) ? kPop : (go_right ? rref : lref);
+                } else if ((int)cur < 0) {
+            // ---- one triangle of the leaf (triangle.cpp:4-54); the ref itself carries the progress
+            float det, inv_det, u, v, dist;
+            if (SRC == 0) {
+                const uint32_t ti = (cur & kLeafStartMask) * 4;
+                const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
+                const float cd = ((const float *)tris)[ti * 4 + 12];
+                // a = (e1, e2.x)  b = (e2.yz, tvec.xy)  c = (tvec.z, qvec)  cd = dot(e2, qvec)
+                float pvx, pvy, pvz;
+                cross3(dx, dy, dz, a.w, b.x, b.y, pvx, pvy, pvz);
+                det = dot3(a.x, a.y, a.z, pvx, pvy, pvz);
+                inv_det = 1.0f / det;
+                u = dot3(b.z, b.w, c.x, pvx, pvy, pvz) * inv_det;
+                v = dot3(dx, dy, dz, c.y, c.z, c.w) * inv_det;
+                dist = cd * inv_det;
+            } else {
+                const uint32_t ti = (cur & kLeafStartMask) * 3;
+                const float4 a = tris[ti], b = tris[ti + 1];
+                const float e2z = ((const float *)tris)[ti * 4 + 8];
+                const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w;
+                float pvx, pvy, pvz;
+                cross3(dx, dy, dz, e2x, e2y, e2z, pvx, pvy, pvz);
+                det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
+                inv_det = 1.0f / det;
+                const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+                u = dot3(tx, ty, tz, pvx, pvy, pvz) * inv_det;
+                float qx, qy, qz;
+                cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+                v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+                dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+            }
+            const bool parallel = fabsf(det) <= 9.99999993922529e-09f;
+            const bool u_out = (u < 0.0f) || (u > 1.0f);
+            const bool v_out = (v < 0.0f) || (u + v > 1.0f);
+            const bool hit = !parallel && !u_out && !v_out && (dist > 0.0f);
+            if (hit && dist < best) {  // strict <: first tested wins ties (bvh.cpp:90)
+                best = dist;
+                slot = (int)(cur & kLeafStartMask);
+            }
+            // next triangle: start + 1, count - 1; after the last one the lane pops
+            cur = (((cur >> kLeafCountShift) & 31u) == 1u) ? kPop : cur + (1u - (1u << kLeafCountShift));
         }
         if (cur == kPop) {
             // pop until an entry passes `near > t` (bvh.cpp:69); level 0 holds the bottom entry
