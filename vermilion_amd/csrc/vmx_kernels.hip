@@ -1785,9 +1785,13 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                 }
                 lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
             }
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            const bool both = h0 && h1;
-            const bool go_right = h1 && (!h0 || (tn1 < tn0));  // both: the strictly closer right child; one: that child
+            // the compares as lane masks (v_cmp into SGPR pairs), combined with scalar ALU ops and handed
+            // back to the lanes as conditions: written with &&/|| hipcc evaluates part of this under
+            // temporary exec masks (fcmp predicates: 5 = ordered <=, 4 = ordered <, 2 = ordered >)
+            const unsigned long long m0 = __builtin_amdgcn_fcmpf(tn0, tf0, 5), m1 = __builtin_amdgcn_fcmpf(tn1, tf1, 5);
+            const unsigned long long m_right = m1 & (~m0 | __builtin_amdgcn_fcmpf(tn1, tn0, 4));
+            const bool both = __builtin_amdgcn_inverse_ballot_w64(m0 & m1);
+            const bool go_right = __builtin_amdgcn_inverse_ballot_w64(m_right);  // both: the strictly closer right child; one: that child
             if (both) {
                 const uint2 e = make_uint2(go_right ? lref : rref, __float_as_uint(go_right ? tn0 : tn1));
                 stack_push(stk, ovf, lds_entries, sp, e);
@@ -1795,7 +1799,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             }
             const float near = go_right ? tn1 : tn0;
             // no child hit, or the child taken directly fails `near > t` (bvh.cpp:69): pop
-            cur = (!(h0 || h1) || (near > best)) ? kPop : (go_right ? rref : lref);
+            const bool popn = __builtin_amdgcn_inverse_ballot_w64(~(m0 | m1) | __builtin_amdgcn_fcmpf(near, best, 2));
+            cur = popn ? kPop : (go_right ? rref : lref);
                 } else if ((int)cur < 0) {
             // ---- one triangle of the leaf (triangle.cpp:4-54); the ref itself carries the progress
             float det, inv_det, u, v, dist;
