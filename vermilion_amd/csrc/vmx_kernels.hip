@@ -205,6 +205,32 @@ __device__ __forceinline__ bool box_exact_rel(float lx, float ly, float lz, floa
     return n <= f;
 }
 
+// min/max network of one box from the six slab products (k_trace_w, k_paths): one asm block, so that no
+// hazard nops land between the pieces; the exact form is the compare-select network of box_exact
+__device__ __forceinline__ void box_net(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z,
+                                        float &tnear, float &tfar) {
+    float n, f, s1, s2;
+    asm("v_min_f32 %0, %4, %7\n\t"
+        "v_min_f32 %2, %5, %8\n\t"
+        "v_min_f32 %3, %6, %9\n\t"
+        "v_max3_f32 %0, %0, %2, %3\n\t"
+        "v_max_f32 %1, %4, %7\n\t"
+        "v_max_f32 %2, %5, %8\n\t"
+        "v_max_f32 %3, %6, %9\n\t"
+        "v_min3_f32 %1, %1, %2, %3"
+        : "=&v"(n), "=&v"(f), "=&v"(s1), "=&v"(s2)
+        : "v"(t0x), "v"(t0y), "v"(t0z), "v"(t1x), "v"(t1y), "v"(t1z));
+    tnear = n;
+    tfar = f;
+}
+__device__ __forceinline__ void box_net_exact(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z,
+                                              float &tnear, float &tfar) {
+    const float sx = sel_min(t0x, t1x), sy = sel_min(t0y, t1y), sz = sel_min(t0z, t1z);
+    const float bx = sel_max(t0x, t1x), by = sel_max(t0y, t1y), bz = sel_max(t0z, t1z);
+    tnear = sel_max(sel_max(sx, sy), sz);
+    tfar = sel_min(sel_min(bx, by), bz);
+}
+
 // ---------------------------------------------------------------------------
 // BVH::getIntersection, nearest hit (bvh.cpp:47-145) + Triangle::getIntersection
 // (triangle.cpp:4-54).  `stk` points at this lane's column of the wave's LDS stack.
@@ -1128,11 +1154,15 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
     bool exhausted = false;
     const uint32_t out_sub = blockIdx.x % kSubQueues;
     // lane state
-    bool has = false, tdone = false, exact = false, is_ray = false;
+    // traversal state as in k_trace_w: `cur` = node reference, kIdle while the lane is not traversing
+    // (no path, or traversal finished and the path waits for shading); stack level 0 = bottom entry
+    constexpr uint32_t kIdle = 0x7FFFFFFFu, kBottom = 0x7FFFFFFEu, kPop = 0x7FFFFFFDu;
+    bool has = false, exact = false, is_ray = false;
     Path P;
-    float ix = 0.f, iy = 0.f, iz = 0.f, best = 0.f, cur_near = 0.f;
+    float ix = 0.f, iy = 0.f, iz = 0.f, best = 0.f;
     int slot = -1, sp = 0;
-    uint32_t cur = 0;
+    uint32_t cur = kIdle;
+    stk[0] = make_uint2(kBottom, 0xFF800000u);
     Cnt c0 = {0, 0}, c1 = {0, 0};
     Tally tl = {{0, 0}, {0, 0}, {0, 0}};
     uint32_t overflow = 0;
@@ -1143,19 +1173,17 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
         is_ray = (P.depth == 0) || finite3(P.dx, P.dy, P.dz);
         best = 999999999.f;  // bvh.cpp:48
         slot = -1;
-        sp = 0;
-        cur = sc.root_ref;
-        cur_near = -9999999.f;  // bvh.cpp:59
-        tdone = false;
+        sp = 1;
+        cur = sc.root_ref;  // its near value, -9999999 (bvh.cpp:59), passes `near > t`
     };
 
     for (;;) {
         // ---- 1. shade the lanes whose traversal is finished ---------------------
         {
-            const unsigned long long fin = __builtin_amdgcn_ballot_w64(has && tdone);
-            const unsigned long long trav = __builtin_amdgcn_ballot_w64(has && !tdone);
+            const unsigned long long fin = __builtin_amdgcn_ballot_w64(has && cur == kIdle);
+            const unsigned long long trav = __builtin_amdgcn_ballot_w64(cur != kIdle);
             if (fin != 0 && ((uint32_t)__popcll(fin) >= wk.shade_min || trav == 0)) {
-                const bool shaded = has && tdone;
+                const bool shaded = has && cur == kIdle;
                 bool alive = false;
                 StepFlags fl = {false, false, false};
                 uint32_t depth0 = 0;
@@ -1250,22 +1278,52 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
             }
         }
         if (__builtin_amdgcn_ballot_w64(has) == 0) break;
-        // ---- 3. up to 8 traversal actions (bvh.cpp:61-134): every traversing lane does its
-        //         triangle step or its inner-node step, then selects its next node --------------
-        for (int act = 0; act < 8; ++act) {
-            const bool trav = has && !tdone;
-            if (__builtin_amdgcn_ballot_w64(trav) == 0) break;
-            const bool at_leaf = trav && (cur & kLeafBit) != 0;
-            bool need_next = false, carry = false;
-            if (at_leaf) {
+        // ---- 3. 8 traversal steps (bvh.cpp:61-134), the step of k_trace_w (see there) with counters:
+        //         every traversing lane does its triangle step or its inner-node step
+        auto step = [&](auto exact_tag) {
+            constexpr bool EXACT = decltype(exact_tag)::value;
+            if (cur < kPop) {
+                const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2];
+                const float2 q3 = ((const float2 *)inner)[cur * 8 + 6];
+                if (COUNT) {
+                    if (P.depth == 0) c0.inner++;
+                    else c1.inner++;
+                }
+                const float a0 = (q0.x - P.ox) * ix, a1 = (q0.y - P.oy) * iy, a2 = (q0.z - P.oz) * iz;
+                const float a3 = (q0.w - P.ox) * ix, a4 = (q1.x - P.oy) * iy, a5 = (q1.y - P.oz) * iz;
+                const float b0 = (q1.z - P.ox) * ix, b1 = (q1.w - P.oy) * iy, b2 = (q2.x - P.oz) * iz;
+                const float b3 = (q2.y - P.ox) * ix, b4 = (q2.z - P.oy) * iy, b5 = (q2.w - P.oz) * iz;
+                float tn0, tf0, tn1, tf1;
+                if (EXACT) {
+                    box_net_exact(a0, a1, a2, a3, a4, a5, tn0, tf0);
+                    box_net_exact(b0, b1, b2, b3, b4, b5, tn1, tf1);
+                } else {
+                    box_net(a0, a1, a2, a3, a4, a5, tn0, tf0);
+                    box_net(b0, b1, b2, b3, b4, b5, tn1, tf1);
+                }
+                const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+                const unsigned long long m0 = __builtin_amdgcn_fcmpf(tn0, tf0, 5), m1 = __builtin_amdgcn_fcmpf(tn1, tf1, 5);
+                const unsigned long long m_right = m1 & (~m0 | __builtin_amdgcn_fcmpf(tn1, tn0, 4));
+                const bool both = __builtin_amdgcn_inverse_ballot_w64(m0 & m1);
+                const bool go_right = __builtin_amdgcn_inverse_ballot_w64(m_right);
+                if (both) {
+                    stack_push(stk, ovf, lds_entries, sp,
+                               make_uint2(go_right ? lref : rref, __float_as_uint(go_right ? tn0 : tn1)));
+                    ++sp;
+                }
+                const float near = go_right ? tn1 : tn0;
+                const bool popn = __builtin_amdgcn_inverse_ballot_w64(~(m0 | m1) | __builtin_amdgcn_fcmpf(near, best, 2));
+                cur = popn ? kPop : (go_right ? rref : lref);
+            } else if ((int)cur < 0) {
                 // one triangle (triangle.cpp:4-54); the leaf ref itself carries the progress
                 const uint32_t ti = (cur & kLeafStartMask) * 3;
-                const float4 a = tris[ti], b = tris[ti + 1], c = tris[ti + 2];
+                const float4 a = tris[ti], b = tris[ti + 1];
+                const float e2z = ((const float *)tris)[ti * 4 + 8];
                 if (COUNT) {
                     if (P.depth == 0) c0.tris++;
                     else c1.tris++;
                 }
-                const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w, e2z = c.x;
+                const float e1x = a.w, e1y = b.x, e1z = b.y, e2x = b.z, e2y = b.w;
                 float pvx, pvy, pvz;
                 cross3(P.dx, P.dy, P.dz, e2x, e2y, e2z, pvx, pvy, pvz);
                 const float det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
@@ -1284,56 +1342,25 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                     best = dist;
                     slot = (int)(cur & kLeafStartMask);
                 }
-                const uint32_t left = ((cur >> kLeafCountShift) & 31u) - 1u;
-                need_next = left == 0;
-                if (!need_next) cur = kLeafBit | (left << kLeafCountShift) | ((cur & kLeafStartMask) + 1u);
+                cur = (((cur >> kLeafCountShift) & 31u) == 1u) ? kPop : cur + (1u - (1u << kLeafCountShift));
             }
-            if (trav && !at_leaf) {
-                const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2],
-                             q3 = inner[cur * 4 + 3];
-                if (COUNT) {
-                    if (P.depth == 0) c0.inner++;
-                    else c1.inner++;
-                }
-                float tn0, tn1;
-                bool h0, h1;
-                if (exact) {
-                    h0 = box_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, P.ox, P.oy, P.oz, ix, iy, iz, tn0);
-                    h1 = box_exact(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, P.ox, P.oy, P.oz, ix, iy, iz, tn1);
-                } else {
-                    h0 = box_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, P.ox, P.oy, P.oz, ix, iy, iz, tn0);
-                    h1 = box_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, P.ox, P.oy, P.oz, ix, iy, iz, tn1);
-                }
-                const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-                const bool both = h0 && h1;  // bvh.cpp:103-132 without branches
-                const bool go_right = both ? (tn1 < tn0) : h1;
-                if (both) {
-                    stack_push(stk, ovf, lds_entries, sp,
-                               make_uint2(go_right ? lref : rref, __float_as_uint(go_right ? tn0 : tn1)));
-                    ++sp;
-                }
-                cur = go_right ? rref : lref;
-                cur_near = go_right ? tn1 : tn0;
-                carry = h0 || h1;
-                need_next = true;
-            }
-            if (need_next) {
-                // next node: the carried child, else pop until an entry passes `near > t` (bvh.cpp:69)
-                if (carry && cur_near > best) carry = false;
-                while (!carry) {
-                    if (sp == 0) {
-                        tdone = true;
-                        break;
-                    }
+            if (cur == kPop) {
+                // pop until an entry passes `near > t` (bvh.cpp:69); the bottom entry always does and
+                // ends the traversal: the lane then waits for shading
+                uint2 e;
+                do {
                     --sp;
-                    const uint2 e = stack_pop(stk, ovf, lds_entries, sp);
-                    if (!(__uint_as_float(e.y) > best)) {
-                        cur = e.x;
-                        cur_near = __uint_as_float(e.y);
-                        carry = true;
-                    }
-                }
+                    e = stack_pop(stk, ovf, lds_entries, sp);
+                } while (__uint_as_float(e.y) > best);
+                cur = e.x == kBottom ? kIdle : e.x;
             }
+        };
+        if (__builtin_amdgcn_ballot_w64(exact && cur != kIdle) != 0) {
+#pragma unroll 1
+            for (int act = 0; act < 8; ++act) step(std::true_type{});
+        } else {
+#pragma unroll 1
+            for (int act = 0; act < 8; ++act) step(std::false_type{});
         }
     }
     tally_flush<COUNT>(ctr, tl, c0, c1);
@@ -1677,30 +1704,6 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 //   * the all-lanes-idle test is made once per 8 steps, not every step.
 // Each ray still performs exactly the reference's sequence of tests (bvh.cpp:47-145).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void box_net(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z,
-                                        float &tnear, float &tfar) {
-    float n, f, s1, s2;
-    asm("v_min_f32 %0, %4, %7\n\t"
-        "v_min_f32 %2, %5, %8\n\t"
-        "v_min_f32 %3, %6, %9\n\t"
-        "v_max3_f32 %0, %0, %2, %3\n\t"
-        "v_max_f32 %1, %4, %7\n\t"
-        "v_max_f32 %2, %5, %8\n\t"
-        "v_max_f32 %3, %6, %9\n\t"
-        "v_min3_f32 %1, %1, %2, %3"
-        : "=&v"(n), "=&v"(f), "=&v"(s1), "=&v"(s2)
-        : "v"(t0x), "v"(t0y), "v"(t0z), "v"(t1x), "v"(t1y), "v"(t1z));
-    tnear = n;
-    tfar = f;
-}
-__device__ __forceinline__ void box_net_exact(float t0x, float t0y, float t0z, float t1x, float t1y, float t1z,
-                                              float &tnear, float &tfar) {
-    const float sx = sel_min(t0x, t1x), sy = sel_min(t0y, t1y), sz = sel_min(t0z, t1z);
-    const float bx = sel_max(t0x, t1x), by = sel_max(t0y, t1y), bz = sel_max(t0z, t1z);
-    tnear = sel_max(sel_max(sx, sy), sz);
-    tfar = sel_min(sel_min(bx, by), bz);
-}
-
 template <int SRC>
 __global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD)
 k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
