@@ -1737,8 +1737,12 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
 
     // One traversal step of every active lane.  The NaN-exact box form runs only while one of the
     // wave's rays needs it.
-    auto step = [&](auto exact_tag) {
+    // base of the node table the wave-uniform steps of this batch read: the wave's octant copy if its
+    // rays share an octant (OCT), else the plain copy; records are addressed by a 32-bit byte offset
+    const char *uni_base = (const char *)inner;
+    auto step = [&](auto exact_tag, auto oct_tag) {
         constexpr bool EXACT = decltype(exact_tag)::value;  // NaN-exact box form
+        constexpr bool OCT = decltype(oct_tag)::value;      // uniform steps read near-plane-first records
         // inner references are the values below kPop; leaf references have bit 31; kPop/kBottom/kIdle lie between
         if (cur < kPop) {
             // ---- inner node: both children boxes (bbox.cpp:70-83), nearer child first (bvh.cpp:103-132)
@@ -1750,22 +1754,18 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                 // and the products take the record straight from SGPRs
                 typedef float f32x4 __attribute__((ext_vector_type(4)));
                 typedef const __attribute__((address_space(4))) f32x4 *scalar_ptr;
-                if (wave_octant < 8) {
-                    // near planes first in this octant's copy: no min/max pairs
-                    const scalar_ptr rec = (scalar_ptr)(uintptr_t)(inner + ((size_t)wave_octant * wk.cam_n_inner + cur0) * 4);
-                    const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                const scalar_ptr rec = (scalar_ptr)(uintptr_t)(uni_base + (uint32_t)(cur0 << 6));
+                const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                if (OCT) {  // near planes first in this octant's copy: no min/max pairs
                     tn0 = vmax3(r0.x * ix, r0.y * iy, r0.z * iz);
                     tf0 = vmin3(r0.w * ix, r1.x * iy, r1.y * iz);
                     tn1 = vmax3(r1.z * ix, r1.w * iy, r2.x * iz);
                     tf1 = vmin3(r2.y * ix, r2.z * iy, r2.w * iz);
-                    lref = __float_as_uint(r3.x), rref = __float_as_uint(r3.y);
                 } else {
-                    const scalar_ptr rec = (scalar_ptr)(uintptr_t)(inner + (size_t)cur0 * 4);
-                    const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                     box_net(r0.x * ix, r0.y * iy, r0.z * iz, r0.w * ix, r1.x * iy, r1.y * iz, tn0, tf0);
                     box_net(r1.z * ix, r1.w * iy, r2.x * iz, r2.y * ix, r2.z * iy, r2.w * iz, tn1, tf1);
-                    lref = __float_as_uint(r3.x), rref = __float_as_uint(r3.y);
                 }
+                lref = __float_as_uint(r3.x), rref = __float_as_uint(r3.y);
             } else {
                 const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2];
                 const float2 q3 = ((const float2 *)inner)[cur * 8 + 6];
@@ -1938,10 +1938,15 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         }
         if (__builtin_amdgcn_ballot_w64(exact && cur != kIdle) != 0) {
 #pragma unroll 1
-            for (int act = 0; act < 8; ++act) step(std::true_type{});
-        } else {
+            for (int act = 0; act < 8; ++act) step(std::true_type{}, std::false_type{});
+        } else if (SRC == 0 && wave_octant < 8) {
+            uni_base = (const char *)inner + (size_t)wave_octant * wk.cam_n_inner * 64;
 #pragma unroll 1
-            for (int act = 0; act < 8; ++act) step(std::false_type{});
+            for (int act = 0; act < 8; ++act) step(std::false_type{}, std::true_type{});
+        } else {
+            uni_base = (const char *)inner;
+#pragma unroll 1
+            for (int act = 0; act < 8; ++act) step(std::false_type{}, std::false_type{});
         }
     }
 }
