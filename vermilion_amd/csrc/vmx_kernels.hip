@@ -1941,8 +1941,9 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             for (int act = 0; act < 8; ++act) step(std::true_type{}, std::false_type{});
         } else if (SRC == 0 && wave_octant < 8) {
             uni_base = (const char *)inner + (size_t)wave_octant * wk.cam_n_inner * 64;
+            // (16 steps per batch here: these waves refill only when all 64 lanes are done; measured 8 / 16 / 32)
 #pragma unroll 1
-            for (int act = 0; act < 8; ++act) step(std::false_type{}, std::true_type{});
+            for (int act = 0; act < 16; ++act) step(std::false_type{}, std::true_type{});
         } else {
             uni_base = (const char *)inner;
 #pragma unroll 1
