@@ -179,7 +179,9 @@ int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32
 #define VMX_BVH_SAH 1u       /* binned-SAH quality tree: same triangle tests and nearest
                                 distance, but exact-distance ties and `near > t` pruning follow ITS order */
 #define VMX_BVH_LBVH 2u      /* linear BVH built on the GPU (Morton sort, Karras hierarchy, bottom-up fit):
-                                milliseconds to build, for scenes that change per frame; same caveat as SAH */
+                                for scenes that change per frame; same caveat as SAH.  Many coincident
+                                centroids can make the tree deeper than the 64-entry traversal stack the
+                                reference allows (bvh.cpp:54): VMX_ERR_DEPTH, use another builder */
 int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                         const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size, uint32_t builder,
                         int device, vmx_scene **out);
