@@ -1,0 +1,94 @@
+"""The three single-precision tests that let the kernels skip the double-precision sphere solve
+(vermilion_amd/csrc/vmx_kernels.hip: sphere_hit_op), restated in numpy and checked against the exact
+evaluation of the reference's formula (meshEngine.cpp:182-194): whenever a test fires, the exact result
+must be one RayCast ignores — 0, or not below the nearest distance so far.  Rays start inside the
+reference's sphere room, ON its walls (where (B*B - C) + R2 cancels at the magnitude of C), and the
+limits are placed right around the exact roots."""
+import numpy as np
+
+f32 = np.float32
+K_REL = f32(9.5367431640625e-07)  # 2^-20, as in the kernel
+
+SPHERES = [((15, 140, 25), 3.5), ((0, 3300, 1300), 250), ((0, -5e7, 0), 5e7), ((0, 5e7 + 1000, 0), 5e7),
+           ((-5e7 + 2000, 0, 0), 5e7), ((5e7 - 2000, 0, 0), 5e7), ((0, 0, -5e7 + 2000), 5e7),
+           ((0, 0, 5e7 - 2000), 5e7), ((100, 200, 300), 50.0), ((0, 0, 0), 1e3), ((5, 5, 5), 1e-2)]
+
+
+def dot3(a, b):  # glm::dot order, one rounding per operation
+    return ((a[:, 0] * b[:, 0]).astype(f32) + (a[:, 1] * b[:, 1]).astype(f32)).astype(f32) + (a[:, 2] * b[:, 2]).astype(f32)
+
+
+def exact_and_shortcuts(o, d, centre, radius, lim):
+    c = np.array(centre, dtype=f32)
+    r2 = f32(f32(radius) * f32(radius))
+    op = (c[None, :] - o).astype(f32)
+    B, C = dot3(op, d).astype(f32), dot3(op, op).astype(f32)
+    b = B.astype(np.float64)
+    det = b * b - C.astype(np.float64) + np.float64(r2)
+    with np.errstate(invalid="ignore"):
+        s = np.sqrt(det)
+    t1, t2 = b - s, b + s
+    th = np.where(det < 0, 0, np.where(t1 > 1e-4, t1, np.where(t2 > 1e-4, t2, 0))).astype(f32)
+    X, BB = (C - r2).astype(f32), (B * B).astype(f32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        tol_m = (K_REL * ((C + r2).astype(f32) + BB).astype(f32)).astype(f32)
+        tol_f = (K_REL * (((C + r2).astype(f32) + BB).astype(f32)
+                          + (lim * ((f32(2) * np.abs(B)).astype(f32) + lim).astype(f32)).astype(f32)).astype(f32)).astype(f32)
+        far = (B > (lim * (f32(1) + K_REL)).astype(f32)) & \
+              ((X - (lim * ((f32(2) * B).astype(f32) - lim).astype(f32)).astype(f32)).astype(f32) > tol_f)
+        miss = BB < (X - tol_m).astype(f32)
+        behind = (B < 0) & (B > -1e11) & (X > tol_m)
+    return th, miss | behind | far
+
+
+def check(o, d, rng):
+    n = o.shape[0]
+    fired = 0
+    for centre, radius in SPHERES:
+        th, _ = exact_and_shortcuts(o, d, centre, radius, np.full(n, np.inf, f32))
+        delta = np.exp(rng.uniform(np.log(1e-8), np.log(1e-1), n)) * rng.choice([-1, 1], n)
+        for lim in (np.full(n, np.inf, f32), (np.where(th > 0, th, rng.uniform(1, 3000, n)) * (1 + delta)).astype(f32)):
+            th, skip = exact_and_shortcuts(o, d, centre, radius, lim)
+            matters = (th > 0) & (th < lim)
+            assert not np.any(skip & matters), (centre, radius)
+            fired += int(skip.sum())
+    return fired
+
+
+def test_shortcuts_never_drop_a_result_that_matters():
+    rng = np.random.default_rng(5)
+    n = 150000
+    # inside the room, aimed anywhere
+    o = np.empty((n, 3), f32)
+    o[:, 0], o[:, 1], o[:, 2] = rng.uniform(-1990, 1990, n), rng.uniform(1, 999, n), rng.uniform(-1990, 1990, n)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    fired = check(o, d.astype(f32), rng)
+    # on the walls (bounce rays start 0.001 off the surface they left), a quarter of them grazing
+    for ax, val in ((0, -2000), (0, 2000), (2, -2000), (2, 2000), (1, 0), (1, 1000)):
+        o2 = o.copy()
+        o2[:, ax] = val + rng.uniform(-0.7, 0.7, n)
+        d2 = rng.normal(size=(n, 3))
+        d2[: n // 4, ax] *= 1e-5
+        d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+        fired += check(o2, d2.astype(f32), rng)
+    assert fired > 1000000  # the shortcuts do fire on this population
+
+
+def test_exact_comparison_would_be_wrong_on_the_walls():
+    """what the margin is for: with `C >= R2` instead of `(C - R2) > tol` the behind test drops real hits"""
+    rng = np.random.default_rng(6)
+    n = 400000
+    o = np.empty((n, 3), f32)
+    o[:, 0], o[:, 1], o[:, 2] = -2000 + rng.uniform(-0.7, 0.7, n), rng.uniform(0, 1000, n), rng.uniform(-2000, 2000, n)
+    d = rng.normal(size=(n, 3))
+    d[:, 0] *= 1e-5
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(f32)
+    c = np.array((5e7 - 2000, 0, 0), dtype=f32)
+    r2 = f32(f32(5e7) * f32(5e7))
+    op = (c[None, :] - o).astype(f32)
+    B, C = dot3(op, d).astype(f32), dot3(op, op).astype(f32)
+    th, _ = exact_and_shortcuts(o, d, (5e7 - 2000, 0, 0), 5e7, np.full(n, np.inf, f32))
+    naive_behind = (B < 0) & (C >= r2)
+    assert np.any(naive_behind & (th > 0))
