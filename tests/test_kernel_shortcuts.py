@@ -1,4 +1,6 @@
-"""The three single-precision tests that let the kernels skip the double-precision sphere solve
+"""Exactness arguments behind two kernel shortcuts, restated in numpy (CPU only).
+
+The three single-precision tests that let the kernels skip the double-precision sphere solve
 (vermilion_amd/csrc/vmx_kernels.hip: sphere_hit_op), restated in numpy and checked against the exact
 evaluation of the reference's formula (meshEngine.cpp:182-194): whenever a test fires, the exact result
 must be one RayCast ignores — 0, or not below the nearest distance so far.  Rays start inside the
@@ -92,3 +94,26 @@ def test_exact_comparison_would_be_wrong_on_the_walls():
     th, _ = exact_and_shortcuts(o, d, (5e7 - 2000, 0, 0), 5e7, np.full(n, np.inf, f32))
     naive_behind = (B < 0) & (C >= r2)
     assert np.any(naive_behind & (th > 0))
+
+
+def test_octant_tables_near_plane_product_is_the_slab_minimum():
+    """k_camera_tables stores, per direction octant, each axis' near plane first, and the wave-uniform
+    step takes max3/min3 of the six products without min/max pairs: for lo <= hi and a finite
+    reciprocal, min(lo*inv, hi*inv) is the product with lo when inv >= 0 and with hi otherwise
+    (float multiplication by a constant is monotonic); only the sign of a zero may differ"""
+    rng = np.random.default_rng(8)
+    n = 2000000
+    a = (rng.normal(size=n) * np.exp(rng.uniform(-20, 20, n))).astype(f32)
+    w = np.abs(rng.normal(size=n) * np.exp(rng.uniform(-20, 20, n))).astype(f32)
+    w[::7] = 0  # degenerate boxes
+    lo, hi = a, (a + w).astype(f32)
+    inv = (rng.normal(size=n) * np.exp(rng.uniform(-30, 30, n))).astype(f32)
+    inv[::11] = 0
+    inv[5::11] = -0.0
+    with np.errstate(over="ignore", invalid="ignore"):
+        t0, t1 = (lo * inv).astype(f32), (hi * inv).astype(f32)
+        neg = np.signbit(inv)
+        near = (np.where(neg, hi, lo) * inv).astype(f32)
+        far = (np.where(neg, lo, hi) * inv).astype(f32)
+    ok = ~(np.isnan(t0) | np.isnan(t1))  # inf * 0: such rays take the exact path in the kernels
+    assert np.all((np.minimum(t0, t1) == near)[ok]) and np.all((np.maximum(t0, t1) == far)[ok])
