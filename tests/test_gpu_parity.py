@@ -97,11 +97,27 @@ def test_primary_hit_triangle_ids_bit_exact(pair):
         assert (tri >= 0).mean() > 0.1
 
 
+# Which kernels a call runs (vmx_api.cpp: render_impl, run_ids):
+#   {}                                  default routing — a pass of < 4 M paths goes to the fused k_paths kernel,
+#                                       bounce generations of <= 16 M live paths to the fused tail (k_paths<2>)
+#   pipeline=4                          the production split wavefront for every pass: k_raygen, k_trace_w<0>
+#                                       (camera rays, incl. the per-octant scalar-fetch path), k_shade<0>; bounces
+#                                       still finish in the fused tail
+#   pipeline=4, tail_threshold=1        ... and every bounce generation through k_trace_w<1> + k_shade<1>
+# so the last two rows put BOTH production traversal kernels of the bench frame directly against the oracle.
+PRODUCTION_FORMS = [{}, {"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1}]
+FORM_IDS = ["default", "split", "split-notail"]
+
+
+@pytest.mark.parametrize("form", PRODUCTION_FORMS, ids=FORM_IDS)
 @pytest.mark.parametrize("sampling", [0, 1])
-def test_radiance_paths_bit_exact(pair, sampling):
+def test_radiance_paths_bit_exact(pair, sampling, form):
+    """vmx_radiance starts from explicit rays, so its first generation already is a *bounce* generation for
+    the kernels: with tail_threshold=1 every generation runs k_trace_w<1> (bvh.cpp:47-145) + k_shade<1>,
+    otherwise the 32 K rays fit the fused tail kernel (k_paths<2>)."""
     c = pair.camf()
     cam = va.make_camera(c["position"], c["rotation_deg"], 256, 128, 16)
-    opts = va.make_opts(seed=5, sampling=sampling, collect_counters=True)
+    opts = va.make_opts(seed=5, sampling=sampling, collect_counters=True, **form)
     o, d = O.primary_rays(cam, opts, 1)
     rad, st = pair.gpu.radiance(o, d, opts)
     rrad, rst = pair.cpu.radiance(o, d, opts)
@@ -111,19 +127,22 @@ def test_radiance_paths_bit_exact(pair, sampling):
     assert st["primary"]["inner_visits"] + st["bounce"]["inner_visits"] == rst["primary"]["inner_visits"]
     assert st["primary"]["tri_tests"] + st["bounce"]["tri_tests"] == rst["primary"]["tri_tests"]
     assert st["primary"]["tri_hits"] + st["bounce"]["tri_hits"] == rst["primary"]["tri_hits"]
-    # production kernels (no counters: k_trace_w) give the same paths
-    rad2, st2 = pair.gpu.radiance(o, d, va.make_opts(seed=5, sampling=sampling))
+    # the same without counters: the instruction-lean kernels (k_trace_w instead of k_trace_q) give the same paths
+    rad2, st2 = pair.gpu.radiance(o, d, va.make_opts(seed=5, sampling=sampling, **form))
     assert np.array_equal(bits(rad2), bits(rrad)) and st2["rays_secondary"] == rst["rays_secondary"]
+    if form.get("tail_threshold") == 1:
+        assert st2["bounce"]["launches"] >= 2 and st2["shade"]["launches"] >= 2  # one trace + one shade per generation
 
 
+@pytest.mark.parametrize("form", PRODUCTION_FORMS, ids=FORM_IDS)
 @pytest.mark.parametrize("early_stop,sampling", [(1, 0), (0, 0), (1, 1), (0, 1)])
-def test_frame_bit_exact(pair, early_stop, sampling):
+def test_frame_bit_exact(pair, early_stop, sampling, form):
     c = pair.camf()
     W, H, spp = (160, 96, 16) if pair.name in ("bunny70k", "sponza260k") else (128, 128, 16)
     if sampling == 1 and pair.name == "sponza260k":
         W, H = 96, 64  # the oracle needs ~25 rays per sample here
     cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
-    opts = va.make_opts(seed=9, early_stop=bool(early_stop), sampling=sampling)
+    opts = va.make_opts(seed=9, early_stop=bool(early_stop), sampling=sampling, **form)
     img, st = pair.gpu.render(cam, opts)
     ref, rst = pair.cpu.render(cam, opts)
     assert img.shape == (H, W, 5)
@@ -135,6 +154,26 @@ def test_frame_bit_exact(pair, early_stop, sampling):
     assert st["samples"] == rst["samples"] == int(img[:, :, 4].sum())
     if not early_stop:
         assert st["samples_discarded"] == 0  # speculation only happens under early stop
+    if form.get("pipeline") == 4:
+        assert st["primary"]["launches"] >= 1 and st["shade"]["launches"] >= 1  # k_trace_w<0> + k_shade<0> ran
+
+
+@pytest.mark.parametrize("form", PRODUCTION_FORMS, ids=FORM_IDS)
+def test_config2_full_frame_bit_exact(form):
+    """BASELINE config 2 at full size — Cornell box 512x512, 64 spp — whole frame against the oracle"""
+    pos, nrm, uv = scenes.cornell8()
+    c = scenes.cornell_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 512, 512, 64, back_size=(3.6, 3.6))
+    p = Pair(pos, nrm, uv)
+    for es in (True, False):
+        opts = va.make_opts(seed=2, early_stop=es, **form)
+        img, st = p.gpu.render(cam, opts)
+        ref, rst = p.cpu.render(cam, opts)
+        assert np.array_equal(bits(img), bits(ref)), (es, form)
+        assert st["samples"] == rst["samples"]
+        if not es:
+            assert st["rays_secondary"] == rst["rays_secondary"] and st["samples"] == 512 * 512 * 64
+    p.close()
 
 
 @pytest.mark.parametrize("spp", [24, 36, 64, 100, 256])
