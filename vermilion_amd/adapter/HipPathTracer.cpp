@@ -20,8 +20,10 @@ bool HipPathTracer::upload(MeshEngine *mEng) {
     for (aiMesh *mesh : mEng->sceneMeshes) faces += mesh->mNumFaces;
     if (mScene && mUploadedFrom == mEng && mUploadedFaces == faces) return true;
     pos.reserve(faces * 9), nrm.reserve(faces * 9), uv.reserve(faces * 6);
-    float lastUv[6] = {0, 0, 0, 0, 0, 0};  // createBVH leaves v*uv untouched for meshes without UVs
     for (aiMesh *mesh : mEng->sceneMeshes) {
+        // createBVH declares v0uv..v2uv per mesh (meshEngine.cpp:663-667) and assigns them only when the
+        // mesh has UVs: a mesh without UVs carries nothing over from the previous mesh (zeros here)
+        float lastUv[6] = {0, 0, 0, 0, 0, 0};
         for (unsigned f = 0; f < mesh->mNumFaces; ++f) {
             for (int c = 0; c < 3; ++c) {
                 const unsigned i = mesh->mFaces[f].mIndices[c];
