@@ -191,7 +191,9 @@ int vmx_scene_destroy(vmx_scene *scene);
  * float image bindTexture would hand to VermiTexture (height rows of width texels of `channels`
  * floats, 1..4 channels, width/height <= 65535 as VermiTexture stores uint16_t).  Only the FIRST
  * bound texture is ever sampled by the path tracer (pathtracer.cpp:63-66: boundTextures[0], wrap
- * + nearest, meshEngine.cpp:21-46); later calls are counted and otherwise ignored, as there.
+ * + nearest, meshEngine.cpp:21-46); the SECOND one is kept for BruteForceTracer, which reads
+ * boundTextures[1] as its albedo (integrators.cpp:141-147); later calls are counted and otherwise
+ * ignored, as there.
  */
 int vmx_scene_bind_texture(vmx_scene *scene, const float *data, uint32_t width, uint32_t height,
                            uint32_t channels);
@@ -250,6 +252,28 @@ int vmx_render_device(const vmx_scene *scene, const vmx_camera *cam, const vmx_o
 int vmx_assemble_device(const void *d_gathered, uint64_t rank_stride_floats, uint32_t width,
                         uint32_t height, uint32_t stripe_rows, uint32_t world, void *d_frame,
                         int device, void *stream);
+
+/* ---- BruteForceTracer: the engine's DEFAULT integrator --------------------
+ * Replaces Vermilion::BruteForceTracer::Render (core/integrators/integrators.cpp:9-186; installed by
+ * RenderEngine::Initialise when no integrator is assigned, core/engines/renderEngine.cpp:49-53):
+ * per pixel up to raysPerPixel jittered camera rays (:59-81), N.L against a point light at
+ * (500,1100,2000) (:16,83-88), the normal perturbed by boundTextures[0] (:98-106), one mirror
+ * probe whose MISS lifts the term to 0.9 N.L + 0.1 (:119-137), albedo from boundTextures[1] or the
+ * constant (0.890196078, 0.258823529, 0.203921569) (:141-156), and a convergence break once more
+ * than two samples are in (:166-172).  Output layout as vmx_render (RGBAZ, camera.cpp:106-113) with
+ * alpha = accum.w / samples (the hit fraction, :180) and depth = the LAST sample's hitDistance
+ * (:181; INFINITY after a miss, meshEngine.cpp:507).  vmx_opts: seed, rank/world/stripe_rows are
+ * used (the jitter of sample s of pixel p comes from the stream keyed (seed, p, s): the reference
+ * shares one time(0)-seeded std::mt19937 between its OpenMP threads, :30, and is not reproducible);
+ * early_stop / sampling / samples_per_batch do not apply.  rays_per_pixel must be 1..65535 (the
+ * reference's loop counter is a uint16_t, :59).
+ */
+#define VMX_BF_ABS_INT 1u /* read the unqualified `abs(float)` of integrators.cpp:170 as C's abs(int) (the sum is
+                             truncated to int first) instead of std::abs(float), the default */
+int vmx_render_bruteforce(const vmx_scene *scene, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
+                          float *out_rgbaz, vmx_stats *stats);
+int vmx_render_bruteforce_device(const vmx_scene *scene, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
+                                 void *d_out_rgbaz, void *stream, vmx_stats *stats);
 
 /* ---- frame output (the step after the path; replaces the conversion loop of
  * Camera::saveFrame, core/camera/camera.cpp:140-175, for the default RGBAZ mode) ------------ */

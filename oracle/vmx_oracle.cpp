@@ -16,6 +16,7 @@
  *   MeshEngine::RayCast             core/engines/meshEngine.cpp:239-509
  *   Radiance                        core/integrators/pathtracer.cpp:21-198
  *   PathTracer::Render              core/integrators/pathtracer.cpp:200-328
+ *   BruteForceTracer::Render        core/integrators/integrators.cpp:9-186
  *   Camera ctor / setPixelValue     core/camera/camera.cpp:34-81, 88-124
  * Each function below cites the lines it follows.
  *
@@ -30,7 +31,7 @@
  * cross, mat4*vec4 as (m0*x + m1*y) + (m2*z + m3*w), gtc rotate); libstdc++'s
  * <random> is used directly where the reference's RNG is wanted.  The only
  * reference-run observations available are the probe results recorded in
- * SURVEY.md (Appendix A-1/A-2/A-9, §8a-6); tests/test_oracle_quirks.py checks
+ * SURVEY.md (Appendix A-1/A-2/A-9, §8a-6); tests/test_oracle.py checks
  * this file against those.
  *
  * Build: see oracle/Makefile.  The parity build is -O2 -ffp-contract=off
@@ -166,6 +167,9 @@ struct orc_scene {
     /* boundTextures[0] (meshEngine.h:62): VermiTexture{nWidth,nHeight,nChannels,pData}, meshEngine.cpp:7-19 */
     std::vector<float> tex;
     uint16_t tex_w = 0, tex_h = 0, tex_c = 0;
+    /* boundTextures[1]: read only by BruteForceTracer (integrators.cpp:141-147) */
+    std::vector<float> tex1;
+    uint16_t tex1_w = 0, tex1_h = 0, tex1_c = 0;
     uint32_t n_textures = 0;
 };
 
@@ -502,19 +506,22 @@ inline bool finite1(float f) {
 inline bool finite3(V3 v) { return finite1(v.x) && finite1(v.y) && finite1(v.z); }
 
 /* VermiTexture::Sample, meshEngine.cpp:21-46: wrap by x - floor(x), nearest by round(x*(W-1)) */
-inline void texture_sample(const orc_scene &sc, V2 uv, V4 *out) {
+inline void texture_sample_of(const float *tex, uint32_t tex_w, uint32_t tex_h, uint32_t tex_c, V2 uv, V4 *out) {
     float sx = uv.x - std::floor(uv.x);
     float sy = uv.y - std::floor(uv.y);
-    uint32_t mx = (uint32_t)std::round(sx * (sc.tex_w - 1));
-    uint32_t my = (uint32_t)std::round(sy * (sc.tex_h - 1));
-    const float *ptr = &sc.tex[((size_t)my * sc.tex_w + mx) * sc.tex_c];
-    switch (sc.tex_c) {
+    uint32_t mx = (uint32_t)std::round(sx * (tex_w - 1));
+    uint32_t my = (uint32_t)std::round(sy * (tex_h - 1));
+    const float *ptr = &tex[((size_t)my * tex_w + mx) * tex_c];
+    switch (tex_c) {
         case 1: *out = V4{ptr[0], ptr[0], ptr[0], ptr[0]}; break;
         case 2: *out = V4{ptr[0], ptr[1], 0, 0}; break;
         case 3: *out = V4{ptr[0], ptr[1], ptr[2], 0}; break;
         case 4: *out = V4{ptr[0], ptr[1], ptr[2], ptr[3]}; break;
         default:;
     }
+}
+inline void texture_sample(const orc_scene &sc, V2 uv, V4 *out) {
+    texture_sample_of(sc.tex.data(), sc.tex_w, sc.tex_h, sc.tex_c, uv, out);
 }
 
 /* Radiance, pathtracer.cpp:21-198.  No texture is bound in any configuration
@@ -702,6 +709,128 @@ void render_rows(const orc_scene &sc, const vmx_camera &cam, const vmx_opts &opt
     }
 }
 
+/* BruteForceTracer::Render, core/integrators/integrators.cpp:9-186 — the engine's default
+ * integrator (renderEngine.cpp:51): N.L from a point light at (500,1100,2000), one mirror probe,
+ * optional normal perturbation by boundTextures[0] and albedo from boundTextures[1], and a
+ * convergence break once more than 2 samples are in.
+ *
+ * Choices where the reference leaves behaviour open (stated in DESIGN.md §8 f-4 as well):
+ *  - RNG.  The reference shares ONE std::mt19937 seeded with time(0) between all OpenMP threads
+ *    without synchronisation (:30,65-66): not reproducible even run to run.  As for PathTracer, sample
+ *    `s` of pixel `p` draws its two jitters from the keyed stream (seed, p, s).
+ *  - `hitMaterial->mNumProperties` (:93-96) is read although RayCast leaves the pointer null when only
+ *    a sphere was hit (meshEngine.cpp:250-251,502-503); the loop body is empty, so no value of it can
+ *    reach the image and an optimising build drops the read.  Not restated.
+ *  - unqualified `abs(float)` (:170) binds to std::abs(float) when <cmath>'s overloads are visible in
+ *    the global namespace (they are with libstdc++ once <stdlib.h>/<math.h> come in, as they do through
+ *    GLM/Assimp) and to C's abs(int) otherwise: VMX_BF_ABS_INT selects the second reading.
+ *  - `resp` (:117-131) is computed and never used (:144 has it commented out): not restated.
+ * depth = hitDistance of the pixel's LAST sample (:181; INFINITY after a miss, meshEngine.cpp:507). */
+void render_bruteforce(const orc_scene &sc, const vmx_camera &cam, const vmx_opts &opts, uint32_t flags, float *out,
+                       vmx_stats *stats, int threads) {
+    const uint32_t W = cam.image_res[0], H = cam.image_res[1], spp = cam.rays_per_pixel;
+    const uint64_t npix = (uint64_t)W * H;
+    const Mat3 M = camera_matrix(cam); /* :23-28, same three rotations as pathtracer.cpp:216-221 */
+    const V3 origin = v3(cam.position[0], cam.position[1], cam.position[2]);
+    const V3 lightLocation = v3(500, 1100, 2000); /* :16 */
+    uint64_t t_prim = 0, t_sec = 0, t_samples = 0, t_hits = 0;
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : t_prim, t_sec, t_samples, t_hits)
+    for (uint64_t p = 0; p < npix; ++p) { /* :32-33 */
+        float hitDistance = 0.f;
+        V4 accum = {0, 0, 0, 0};
+        uint32_t nTotalSamples = 0;
+        V4 lastSampleColour = {0, 0, 0, 0};
+        V4 currentSampleColour = {0, 0, 0, 0};
+        for (uint16_t sample = 0; sample < spp; ++sample) { /* :59 */
+            ++nTotalSamples;
+            Xoshiro rng;
+            rng.init(opts.seed, (uint32_t)p, sample);
+            const float jx = rng.jitter(), jy = rng.jitter();
+            float homogenousX = (float)(((float(p % W) + jx - 0.25) / W) * 2 - 1); /* :65 */
+            float homogenousY = (float)(((float(p / W) + jy - 0.25) / H) * 2 - 1); /* :66 */
+            float cameraBackXCm = (float)(homogenousX * cam.back_size[0] * 0.5);   /* :73 */
+            float cameraBackYCm = (float)(homogenousY * cam.back_size[1] * 0.5);   /* :74 */
+            float gx = cameraBackXCm, gy = -cameraBackYCm, gz = -cam.back_distance; /* :76, w = 1 */
+            V3 raw = (M.c0 * gx + M.c1 * gy) + (M.c2 * gz + v3(0, 0, 0) * 1.0f);  /* :79 */
+            float w = (0.f * gx + 0.f * gy) + (0.f * gz + 1.f * 1.0f);
+            V3 dir = normalize(raw / w); /* :81 */
+            ++t_prim;
+            CastOut c = ray_cast(sc, origin, dir, nullptr); /* :81 */
+            hitDistance = c.distance;
+            if (c.hit) {
+                if (c.tri_id >= 0) ++t_hits;
+                V3 hitNormal = c.normal;
+                V3 lightDirectionVector = lightLocation - c.location; /* :83 */
+                V3 lightDirection = normalize(lightDirectionVector);   /* :84 */
+                float vNDL = dot(lightDirection, normalize(hitNormal)); /* :88 */
+                if (sc.n_textures > 0) { /* :98-106 */
+                    V4 normal = {0, 0, 0, 0};
+                    texture_sample(sc, c.uv, &normal);
+                    hitNormal = hitNormal + v3(normal.x, normal.y, normal.z);
+                    vNDL = dot(lightDirection, normalize(hitNormal));
+                }
+                /* :119  -L - 2.f * N * dot(N, -L): (2.f * N) is formed first, then scaled */
+                V3 negL = -lightDirection;
+                V3 secondBounceDirection = negL - (v3(2.f * hitNormal.x, 2.f * hitNormal.y, 2.f * hitNormal.z) * dot(hitNormal, negL));
+                if (finite3(secondBounceDirection)) ++t_sec;
+                CastOut c2 = ray_cast(sc, c.location, secondBounceDirection, nullptr); /* :121 */
+                if (!c2.hit) { /* :133-137 */
+                    vNDL *= 0.9f;
+                    vNDL += 0.1f;
+                }
+                if (sc.n_textures > 1) { /* :141-147 */
+                    texture_sample_of(sc.tex1.data(), sc.tex1_w, sc.tex1_h, sc.tex1_c, c.uv, &currentSampleColour);
+                    currentSampleColour = V4{currentSampleColour.x * vNDL, currentSampleColour.y * vNDL,
+                                             currentSampleColour.z * vNDL, currentSampleColour.w * vNDL};
+                    currentSampleColour.w = 1.0;
+                } else { /* :148-156 */
+                    currentSampleColour = V4{0.890196078f * vNDL, 0.258823529f * vNDL, 0.203921569f * vNDL, 1.0};
+                }
+                accum = accum + currentSampleColour; /* :158 */
+            }
+            if (nTotalSamples > 2) { /* :167-172 */
+                const float n = float(nTotalSamples); /* glm::vec4(nTotalSamples) */
+                lastSampleColour = V4{lastSampleColour.x - accum.x / n, lastSampleColour.y - accum.y / n,
+                                      lastSampleColour.z - accum.z / n, lastSampleColour.w - accum.w / n};
+                const float sum = lastSampleColour.x + lastSampleColour.y + lastSampleColour.z + lastSampleColour.w;
+                float mag;
+                if (flags & VMX_BF_ABS_INT) {
+                    /* abs(int): the float converts to int first (values outside int's range: undefined there, 0 here) */
+                    const double tr = std::trunc((double)sum);
+                    mag = (tr >= -2147483648.0 && tr <= 2147483647.0) ? (float)std::abs((int)tr) : 0.f;
+                } else {
+                    mag = std::fabs(sum);
+                }
+                if (mag < 0.001f) break;
+            }
+            {
+                const float n = float(nTotalSamples); /* :173 */
+                lastSampleColour = V4{accum.x / n, accum.y / n, accum.z / n, accum.w / n};
+            }
+        }
+        float *px = out + p * 5; /* :176-183, camera.cpp:106-113 (RGBAZ) */
+        px[0] = std::max(std::min(accum.x / nTotalSamples, 1.f), 0.f);
+        px[1] = std::max(std::min(accum.y / nTotalSamples, 1.f), 0.f);
+        px[2] = std::max(std::min(accum.z / nTotalSamples, 1.f), 0.f);
+        px[3] = accum.w / nTotalSamples;
+        px[4] = hitDistance;
+        t_samples += nTotalSamples;
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->rays_primary = t_prim;
+        stats->rays_secondary = t_sec;
+        stats->samples = t_samples;
+        stats->primary.rays = t_prim + t_sec;
+        stats->primary.tri_hits = t_hits;
+    }
+}
+
 } // namespace
 
 /* ------------------------------------------------------------------ */
@@ -787,6 +916,9 @@ int orc_scene_bind_texture(orc_scene *sc, const float *data, uint32_t w, uint32_
     if (sc->n_textures == 0) {
         sc->tex.assign(data, data + (size_t)w * h * c);
         sc->tex_w = (uint16_t)w, sc->tex_h = (uint16_t)h, sc->tex_c = (uint16_t)c;
+    } else if (sc->n_textures == 1) { /* boundTextures[1]: BruteForceTracer's albedo (integrators.cpp:141-147) */
+        sc->tex1.assign(data, data + (size_t)w * h * c);
+        sc->tex1_w = (uint16_t)w, sc->tex1_h = (uint16_t)h, sc->tex1_c = (uint16_t)c;
     }
     sc->n_textures++;
     return 0;
@@ -967,6 +1099,13 @@ void orc_render(const orc_scene *sc, const vmx_camera *cam, const vmx_opts *opts
         render_rows<Xoshiro>(*sc, *cam, *opts, out_rgbaz, stats, threads,
                              [seed](Xoshiro &r, uint64_t p, uint32_t k) { r.init(seed, (uint32_t)p, k); });
     }
+}
+
+/* BruteForceTracer::Render (integrators.cpp:9-186), keyed jitter streams; W*H*5 floats
+ * (r, g, b, alpha = hit fraction, depth = last sample's hit distance) */
+void orc_render_bruteforce(const orc_scene *sc, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
+                           int threads, float *out_rgbaz, vmx_stats *stats) {
+    render_bruteforce(*sc, *cam, *opts, flags, out_rgbaz, stats, threads);
 }
 
 } /* extern "C" */

@@ -71,6 +71,9 @@ uint64_t orc_splitmix64(uint64_t *state);
 /* PathTracer::Render — whole image, W*H*5 floats RGBAZ.  threads 0 -> OpenMP default */
 void orc_render(const orc_scene *, const vmx_camera *cam, const vmx_opts *opts, int rng_mode,
                 int threads, float *out_rgbaz, vmx_stats *stats);
+/* BruteForceTracer::Render (integrators.cpp:9-186); flags: VMX_BF_* of vermilion_hip.h */
+void orc_render_bruteforce(const orc_scene *, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
+                           int threads, float *out_rgbaz, vmx_stats *stats);
 int orc_max_threads(void);
 /* Camera::saveFrame conversion (camera.cpp:159-163) */
 void orc_quantize(const float *frame, uint64_t npix, unsigned char *rgba8, float *depth);

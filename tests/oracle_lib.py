@@ -60,6 +60,8 @@ def lib(fast=False):
     l.orc_splitmix64.argtypes = [C.POINTER(C.c_uint64)]
     l.orc_render.argtypes = [P, C.POINTER(L.CameraDesc), C.POINTER(L.Opts), C.c_int, C.c_int, P,
                              C.POINTER(L.Stats)]
+    l.orc_render_bruteforce.argtypes = [P, C.POINTER(L.CameraDesc), C.POINTER(L.Opts), C.c_uint32, C.c_int, P,
+                                        C.POINTER(L.Stats)]
     l.orc_max_threads.restype = C.c_int
     l.orc_quantize.argtypes = [P, C.c_uint64, P, P]
     _libs[name] = l
@@ -158,6 +160,15 @@ class OracleScene:
         self.l.orc_radiance_mt(self.h, o.ctypes.data, d.ctypes.data, o.shape[0], seeds.ctypes.data, sampling,
                                out.ctypes.data)
         return out
+
+    def render_bruteforce(self, cam, opts, flags=0, threads=0):
+        """BruteForceTracer::Render restated (integrators.cpp:9-186), whole image [H, W, 5]"""
+        W, H = cam.image_res[0], cam.image_res[1]
+        out = np.empty((H, W, 5), np.float32)
+        st = L.Stats()
+        self.l.orc_render_bruteforce(self.h, C.byref(cam), C.byref(opts), int(flags), threads, out.ctypes.data,
+                                     C.byref(st))
+        return out, st.as_dict()
 
     def render(self, cam, opts, rng_mode=ORC_RNG_XOSHIRO_KEYED, threads=0):
         W, H = cam.image_res[0], cam.image_res[1]

@@ -294,3 +294,48 @@ def test_bvh_statistics_match_the_survey_probe():
     tri, t, c = O.OracleScene(*scenes.heightfield(187)).trace(oo, dd.astype(np.float32), counters=True)
     assert (tri >= 0).mean() > 0.99
     assert 10 < c["inner_visits"] / 20000 < 22 and 3 < c["tri_tests"] / 20000 < 7 and c["max_stack"] <= 12
+
+
+# ---- BruteForceTracer restatement (integrators.cpp:9-186) -----------------------------------
+def test_bruteforce_known_answers():
+    """hand-derived: a camera looking straight down at the floor sphere from the middle of the room —
+    every ray hits the floor (y = 0, normal +y): N.L = L.y with L = normalize((500,1100,2000) - hit), the
+    mirror probe leaves through nothing but walls (always a hit), so the colour is the constant albedo
+    (0.890196078, 0.258823529, 0.203921569) * N.L (:148-156), alpha 1, and the break (:166-172) fires at
+    the third sample because neighbouring sub-pixel samples differ by far less than 0.001"""
+    pos, nrm, uv = scenes.cornell8()
+    far = (pos + np.float32([5000, 0, 0] * 3)).astype(np.float32)  # move the mesh out of the way (outside the room)
+    sc = O.OracleScene(far, nrm, uv)
+    cam = va.make_camera((0, 500, 0), (90, 0, 0), 8, 8, 16, back_distance=6.0, back_size=(0.2, 0.2))  # looks straight down
+    img, st = sc.render_bruteforce(cam, va.make_opts(seed=1))
+    assert st["samples"] == 3 * 64 and np.all(img[:, :, 3] == 1.0)
+    # the floor sphere's catastrophic cancellation (r = 5e7) puts the hit at ~499.29 instead of 500 (SURVEY §8a-6)
+    assert np.all(np.abs(img[:, :, 4] - 499.3) < 0.7)
+    L = np.array([500.0, 1100.0, 2000.0]) - np.array([0.0, 0.0, 0.0])
+    ndl = L[1] / np.linalg.norm(L)
+    want = np.array([0.890196078, 0.258823529, 0.203921569]) * ndl
+    assert np.allclose(img[:, :, :3].reshape(-1, 3), want, atol=4e-3)  # (the hits are ~0.6 above y = 0 and up to 8 off the axis)
+    # the other reading of `abs` (:170): abs(int) truncates, so every |sum| < 1 counts as converged
+    img2, st2 = sc.render_bruteforce(cam, va.make_opts(seed=1), flags=va._lib.VMX_BF_ABS_INT)
+    assert st2["samples"] == 3 * 64
+    # no hit at all (no spheres, mesh far away): accum = 0, alpha 0, depth INFINITY, 3 samples
+    none = (va._lib.Sphere * 0)()
+    sc0 = O.OracleScene(far, nrm, uv, spheres=none)
+    img0, st0 = sc0.render_bruteforce(cam, va.make_opts(seed=1))
+    assert np.all(img0[:, :, :4] == 0) and np.all(np.isinf(img0[:, :, 4])) and st0["samples"] == 3 * 64
+    assert st0["rays_secondary"] == 0
+
+
+def test_bruteforce_break_needs_more_than_two_samples_and_is_seed_keyed():
+    pos, nrm, uv = scenes.lattice()
+    sc = O.OracleScene(pos, nrm, uv)
+    c = scenes.lattice_camera()
+    for spp in (1, 2, 3, 7):
+        img, st = sc.render_bruteforce(va.make_camera(c["position"], c["rotation_deg"], 24, 16, spp), va.make_opts(seed=5))
+        assert st["samples"] == 24 * 16 * spp if spp <= 2 else 24 * 16 * 3 <= st["samples"] <= 24 * 16 * spp
+    cam = va.make_camera(c["position"], c["rotation_deg"], 24, 16, 12)
+    a, _ = sc.render_bruteforce(cam, va.make_opts(seed=5))
+    b, _ = sc.render_bruteforce(cam, va.make_opts(seed=5), threads=1)
+    d, _ = sc.render_bruteforce(cam, va.make_opts(seed=6))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # keyed streams: thread-count independent
+    assert not np.array_equal(a.view(np.uint32), d.view(np.uint32))

@@ -23,6 +23,7 @@ VMX_SAMPLING_CORRECTED = 1
 VMX_BVH_REFERENCE = 0
 VMX_BVH_SAH = 1
 VMX_BVH_LBVH = 2
+VMX_BF_ABS_INT = 1
 
 
 class Sphere(C.Structure):
@@ -150,6 +151,9 @@ SYMBOLS = {
     "vmx_local_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "vmx_render": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),
     "vmx_render_device": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, _P, C.POINTER(Stats)]),
+    "vmx_render_bruteforce": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), C.c_uint32, _P, C.POINTER(Stats)]),
+    "vmx_render_bruteforce_device": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), C.c_uint32, _P, _P,
+                                              C.POINTER(Stats)]),
     "vmx_quantize_device": (C.c_int, [_P, C.c_uint64, _P, _P, C.c_int, _P]),
     "vmx_assemble_device": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_int, _P]),
 }

@@ -1,4 +1,4 @@
-// HipPathTracer.cpp — see HipPathTracer.h.  Marshals the reference's objects
+// HipPathTracer.cpp — see HipPathTracer.h.  Marshal the reference's objects
 // into the plain-C ABI of include/vermilion_hip.h; no rendering happens here.
 #include "HipPathTracer.h"
 
@@ -8,17 +8,18 @@
 
 namespace Vermilion {
 
-HipPathTracer::~HipPathTracer() { vmx_scene_destroy(mScene); }
+HipIntegratorBase::~HipIntegratorBase() { vmx_scene_destroy(mScene); }
 
 // Flatten MeshEngine::sceneMeshes exactly as MeshEngine::createBVH does
 // (core/engines/meshEngine.cpp:660-718): mesh-major, face-minor; that push
 // order defines the triangle IDs.  BVH internals are private (bvh.h:19-26),
 // so the library builds its own BVH with the same topology.
-bool HipPathTracer::upload(MeshEngine *mEng) {
+bool HipIntegratorBase::upload(MeshEngine *mEng) {
     std::vector<float> pos, nrm, uv;
     size_t faces = 0;
     for (aiMesh *mesh : mEng->sceneMeshes) faces += mesh->mNumFaces;
-    if (mScene && mUploadedFrom == mEng && mUploadedFaces == faces) return true;
+    if (mScene && mUploadedFrom == mEng && mUploadedFaces == faces && mUploadedTextures == mEng->boundTextures.size())
+        return true;
     pos.reserve(faces * 9), nrm.reserve(faces * 9), uv.reserve(faces * 6);
     for (aiMesh *mesh : mEng->sceneMeshes) {
         // createBVH declares v0uv..v2uv per mesh (meshEngine.cpp:663-667) and assigns them only when the
@@ -44,31 +45,48 @@ bool HipPathTracer::upload(MeshEngine *mEng) {
         std::fprintf(stderr, "HipPathTracer: %s\n", vmx_last_error());
         return false;
     }
-    // boundTextures[0] is the only texture Radiance samples (pathtracer.cpp:63-66)
-    if (!mEng->boundTextures.empty()) {
-        const VermiTexture &tx = mEng->boundTextures[0];
+    // boundTextures[0] is the only texture Radiance samples (pathtracer.cpp:63-66); BruteForceTracer also
+    // reads boundTextures[1] (integrators.cpp:141-147).  Bound in order, as MeshEngine::bindTexture appends.
+    for (size_t t = 0; t < mEng->boundTextures.size() && t < 2; ++t) {
+        const VermiTexture &tx = mEng->boundTextures[t];
         if (vmx_scene_bind_texture(mScene, tx.pData, tx.nWidth, tx.nHeight, tx.nChannels) != VMX_OK)
-            std::fprintf(stderr, "HipPathTracer: %s\n", vmx_last_error());
+            std::fprintf(stderr, "vermilion_hip: %s\n", vmx_last_error());
     }
     mUploadedFrom = mEng;
     mUploadedFaces = faces;
+    mUploadedTextures = mEng->boundTextures.size();
     return true;
+}
+
+vmx_camera HipIntegratorBase::describe(const Camera *cam) {
+    vmx_camera c;
+    std::memset(&c, 0, sizeof(c));
+    c.position[0] = cam->mPosition.x, c.position[1] = cam->mPosition.y, c.position[2] = cam->mPosition.z;
+    // Camera stores radians with x,y negated (camera.cpp:43-47); the ABI takes cameraSettings' degrees
+    c.rotation_deg[0] = (float)(-cam->mRotation.x * 180 / 3.1415926535);
+    c.rotation_deg[1] = (float)(-cam->mRotation.y * 180 / 3.1415926535);
+    c.rotation_deg[2] = (float)(cam->mRotation.z * 180 / 3.1415926535);
+    c.back_distance = cam->mDistToFilm;
+    c.back_size[0] = cam->sensorSizeX, c.back_size[1] = cam->sensorSizeY;
+    c.image_res[0] = cam->uImageU, c.image_res[1] = cam->uImageV;
+    c.rays_per_pixel = cam->uSamplesPerPixel;
+    return c;
+}
+
+void HipIntegratorBase::writeBack(Camera *cam, const std::vector<float> &frame) {
+    pixelValue pv;                                           // camera.h:49-58
+    pv.light = 0.f;
+    for (uint64_t p = 0; p < cam->RenderTargetSize; ++p) {   // works for every renderMode (camera.cpp:88-124)
+        const float *s = &frame[p * 5];
+        pv.pixel = p, pv.red = s[0], pv.green = s[1], pv.blue = s[2], pv.alpha = s[3], pv.depth = s[4];
+        cam->setPixelValue(pv);
+    }
 }
 
 void HipPathTracer::Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) {
     if (!mEng || !upload(mEng)) return;  // Render has no error channel (integrators.h:15): log and leave mImage untouched
     for (Camera *cam : cameraList) {     // pathtracer.cpp:210
-        vmx_camera c;
-        std::memset(&c, 0, sizeof(c));
-        c.position[0] = cam->mPosition.x, c.position[1] = cam->mPosition.y, c.position[2] = cam->mPosition.z;
-        // Camera stores radians with x,y negated (camera.cpp:43-47); the ABI takes cameraSettings' degrees
-        c.rotation_deg[0] = (float)(-cam->mRotation.x * 180 / 3.1415926535);
-        c.rotation_deg[1] = (float)(-cam->mRotation.y * 180 / 3.1415926535);
-        c.rotation_deg[2] = (float)(cam->mRotation.z * 180 / 3.1415926535);
-        c.back_distance = cam->mDistToFilm;
-        c.back_size[0] = cam->sensorSizeX, c.back_size[1] = cam->sensorSizeY;
-        c.image_res[0] = cam->uImageU, c.image_res[1] = cam->uImageV;
-        c.rays_per_pixel = cam->uSamplesPerPixel;
+        const vmx_camera c = describe(cam);
         vmx_opts o;
         std::memset(&o, 0, sizeof(o));
         o.seed = mSeed;
@@ -81,12 +99,25 @@ void HipPathTracer::Render(std::vector<Vermilion::Camera *> &cameraList, MeshEng
             continue;
         }
         cam->uRaysFired = st.rays_primary + st.rays_secondary;  // camera.h:101 (the reference never fills it)
-        pixelValue pv;                                           // camera.h:49-58
-        for (uint64_t p = 0; p < cam->RenderTargetSize; ++p) {   // works for every renderMode (camera.cpp:88-124)
-            const float *s = &frame[p * 5];
-            pv.pixel = p, pv.red = s[0], pv.green = s[1], pv.blue = s[2], pv.alpha = s[3], pv.depth = s[4];
-            cam->setPixelValue(pv);
+        writeBack(cam, frame);
+    }
+}
+
+void HipBruteForceTracer::Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) {
+    if (!mEng || !upload(mEng)) return;
+    for (Camera *cam : cameraList) {  // integrators.cpp:21
+        const vmx_camera c = describe(cam);
+        vmx_opts o;
+        std::memset(&o, 0, sizeof(o));
+        o.seed = mSeed;
+        std::vector<float> frame((size_t)cam->RenderTargetSize * 5);
+        vmx_stats st;
+        if (vmx_render_bruteforce(mScene, &c, &o, mFlags, frame.data(), &st) != VMX_OK) {
+            std::fprintf(stderr, "HipBruteForceTracer: %s\n", vmx_last_error());
+            continue;
         }
+        cam->uRaysFired = st.rays_primary + st.rays_secondary;
+        writeBack(cam, frame);  // red/green/blue clamped, alpha = hit fraction, depth = last hitDistance (integrators.cpp:176-183)
     }
 }
 

@@ -1,11 +1,11 @@
-// HipPathTracer.h — the reference-side adapter: a Vermilion::Integrator whose
+// HipPathTracer.h — the reference-side adapters: Vermilion::Integrator subclasses whose
 // Render() runs on an MI355X through libvermilion_hip.so.
 //
 // Built as part of Vermilion (add to SOURCE_FILES in CMakeLists.txt and link
-// vermilion_hip); it is NOT compiled in this repository's image because it
-// includes the reference's own headers, which need GLM/Assimp/OpenImageIO.
+// vermilion_hip).  This repository's image has no GLM/Assimp/OpenImageIO, so here the file only goes
+// through a syntax + type check against the reference's own headers (tests/test_adapter_compiles.py).
 //
-// Replaces: Vermilion::PathTracer (core/integrators/integrators.h:23-26,
+// HipPathTracer replaces Vermilion::PathTracer (core/integrators/integrators.h:23-26,
 // core/integrators/pathtracer.cpp:200-328).  Installed exactly like it:
 //     auto integrator = new Vermilion::HipPathTracer();   // main.cpp:61
 //     rEng->assignIntegrator(integrator);                 // main.cpp:63
@@ -15,20 +15,43 @@
 
 namespace Vermilion {
 
-class HipPathTracer : public Integrator {
+// what both adapters share: the device copy of MeshEngine's triangles / textures, the camera marshalling
+// and the pixel write-back through Camera::setPixelValue
+class HipIntegratorBase : public Integrator {
    public:
-    // seed: the reference seeds from std::random_device (pathtracer.cpp:231)
-    explicit HipPathTracer(uint64_t seed = 1, int device = 0) : mSeed(seed), mDevice(device) {}
-    ~HipPathTracer() override;
-    void Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) override;
+    // seed: the reference seeds from std::random_device (pathtracer.cpp:231) / time(0) (integrators.cpp:30)
+    explicit HipIntegratorBase(uint64_t seed, int device) : mSeed(seed), mDevice(device) {}
+    ~HipIntegratorBase() override;
 
-   private:
+   protected:
     bool upload(MeshEngine *mEng);
+    static vmx_camera describe(const Camera *cam);
+    static void writeBack(Camera *cam, const std::vector<float> &frame);
     uint64_t mSeed;
     int mDevice;
     vmx_scene *mScene = nullptr;
     const MeshEngine *mUploadedFrom = nullptr;
-    size_t mUploadedFaces = 0;
+    size_t mUploadedFaces = 0, mUploadedTextures = 0;
+};
+
+class HipPathTracer : public HipIntegratorBase {
+   public:
+    explicit HipPathTracer(uint64_t seed = 1, int device = 0) : HipIntegratorBase(seed, device) {}
+    void Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) override;
+};
+
+// Replaces Vermilion::BruteForceTracer (core/integrators/integrators.h:18-21,
+// core/integrators/integrators.cpp:9-186), the integrator RenderEngine::Initialise installs when
+// none is assigned (core/engines/renderEngine.cpp:49-53).
+class HipBruteForceTracer : public HipIntegratorBase {
+   public:
+    // absAsInt: read the unqualified abs() of integrators.cpp:170 as C's abs(int) (VMX_BF_ABS_INT)
+    explicit HipBruteForceTracer(uint64_t seed = 1, int device = 0, bool absAsInt = false)
+        : HipIntegratorBase(seed, device), mFlags(absAsInt ? VMX_BF_ABS_INT : 0u) {}
+    void Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) override;
+
+   private:
+    uint32_t mFlags;
 };
 
 }  // namespace Vermilion

@@ -135,11 +135,13 @@ struct vmx_scene {
     HostBvh bvh;
     uint32_t ntris = 0, leaf_size = 4;
     std::vector<vmx_sphere> spheres;
-    DevBuf<InnerRecord> d_inner;
-    DevBuf<TriRecord> d_tris;
+    // inner records, then (64-byte aligned) the triangle records, in ONE allocation: a lane of the bounce
+    // traversal kernel addresses either kind of record with a 32-bit byte offset from `dev.inner`
+    // (SceneDev::tri_off), so inner-node lanes and leaf lanes of a wave fetch in one set of loads
+    DevBuf<unsigned char> d_geom;
     DevBuf<AttrRecord> d_attrs;
     DevBuf<SphereDev> d_spheres;
-    DevBuf<float> d_tex;
+    DevBuf<float> d_tex, d_tex1;
     uint32_t n_textures = 0;
     SceneDev dev{};
     hipStream_t stream = nullptr;
@@ -349,6 +351,10 @@ LaunchCfg paths_cfg(const vmx_scene *sc, uint32_t entries, uint64_t items, int b
     c.block = kPathsBlock;
     c.lds_bytes = (kPathsBlock / 64) * (entries + 1) * 512;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (const char *e = std::getenv("VMX_EXP_BLOCKS")) {  // EXPERIMENT: cap blocks per CU of the persistent kernels
+        const int cap = std::atoi(e);
+        if (cap > 0 && cap < blocks_per_cu) blocks_per_cu = cap;
+    }
     uint64_t grid = (uint64_t)sc->num_cus * (uint64_t)blocks_per_cu;
     const uint64_t need = (items + kPathsBlock - 1) / kPathsBlock;
     if (need < grid) grid = std::max<uint64_t>(1, need);
@@ -810,20 +816,26 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
         d.flags = s.flags;
     }
     const HostBvh &b = sc->bvh;
-    if (sc->d_inner.ensure(std::max<size_t>(b.inner.size(), 1)) || sc->d_tris.ensure(b.tris.size()) ||
+    const size_t inner_bytes = std::max<size_t>(b.inner.size(), 1) * sizeof(InnerRecord);
+    const size_t tri_bytes = b.tris.size() * sizeof(TriRecord);
+    // + 64: the unified fetch reads 56 bytes from a 48-byte triangle record's start
+    if (inner_bytes + tri_bytes + 64 > 0xFFFFFFFFull) return bail(VMX_ERR_INVALID, "scene too large for 32-bit record offsets");
+    if (sc->d_geom.ensure(inner_bytes + tri_bytes + 64) ||
         sc->d_attrs.ensure(b.attrs.size()) || sc->d_spheres.ensure(std::max<size_t>(sd.size(), 1)))
         return bail(VMX_ERR_NOMEM, "hipMalloc failed for the scene");
-    if ((b.inner.size() && hipMemcpy(sc->d_inner.p, b.inner.data(), b.inner.size() * sizeof(InnerRecord),
+    if (hipMemset(sc->d_geom.p, 0, inner_bytes + tri_bytes + 64) != hipSuccess) return bail(VMX_ERR_HIP, "hipMemset failed");
+    if ((b.inner.size() && hipMemcpy(sc->d_geom.p, b.inner.data(), b.inner.size() * sizeof(InnerRecord),
                                      hipMemcpyHostToDevice) != hipSuccess) ||
-        hipMemcpy(sc->d_tris.p, b.tris.data(), b.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice) !=
+        hipMemcpy(sc->d_geom.p + inner_bytes, b.tris.data(), tri_bytes, hipMemcpyHostToDevice) !=
             hipSuccess ||
         hipMemcpy(sc->d_attrs.p, b.attrs.data(), b.attrs.size() * sizeof(AttrRecord), hipMemcpyHostToDevice) !=
             hipSuccess ||
         (sd.size() && hipMemcpy(sc->d_spheres.p, sd.data(), sd.size() * sizeof(SphereDev),
                                 hipMemcpyHostToDevice) != hipSuccess))
         return bail(VMX_ERR_HIP, "scene upload failed");
-    sc->dev.inner = sc->d_inner.p;
-    sc->dev.tris = sc->d_tris.p;
+    sc->dev.inner = sc->d_geom.p;
+    sc->dev.tris = sc->d_geom.p + inner_bytes;
+    sc->dev.tri_off = (uint32_t)inner_bytes;
     sc->dev.attrs = sc->d_attrs.p;
     sc->dev.spheres = sc->d_spheres.p;
     sc->dev.root_ref = b.root_ref;
@@ -841,8 +853,8 @@ int vmx_scene_destroy(vmx_scene *sc) {
     if (!sc) return VMX_OK;
     (void)hipSetDevice(sc->device);
     sc->ws.release();
-    sc->d_inner.release(), sc->d_tris.release(), sc->d_attrs.release(), sc->d_spheres.release();
-    sc->d_tex.release();
+    sc->d_geom.release(), sc->d_attrs.release(), sc->d_spheres.release();
+    sc->d_tex.release(), sc->d_tex1.release();
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
     return VMX_OK;
@@ -855,12 +867,18 @@ int vmx_scene_bind_texture(vmx_scene *sc, const float *data, uint32_t width, uin
     std::lock_guard<std::mutex> lock(sc->mu);
     int rc = bind_device(sc);
     if (rc) return rc;
-    if (sc->n_textures == 0) {  // only boundTextures[0] is sampled (pathtracer.cpp:65)
+    if (sc->n_textures == 0) {  // only boundTextures[0] is sampled by PathTracer (pathtracer.cpp:65)
         const size_t n = (size_t)width * height * channels;
         if (sc->d_tex.ensure(n)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the texture");
         HIP_TRY(hipMemcpy(sc->d_tex.p, data, n * 4, hipMemcpyHostToDevice));
         sc->dev.tex = sc->d_tex.p;
         sc->dev.tex_w = width, sc->dev.tex_h = height, sc->dev.tex_c = channels;
+    } else if (sc->n_textures == 1) {  // boundTextures[1]: BruteForceTracer's albedo (integrators.cpp:141-147)
+        const size_t n = (size_t)width * height * channels;
+        if (sc->d_tex1.ensure(n)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the texture");
+        HIP_TRY(hipMemcpy(sc->d_tex1.p, data, n * 4, hipMemcpyHostToDevice));
+        sc->dev.tex1 = sc->d_tex1.p;
+        sc->dev.tex1_w = width, sc->dev.tex1_h = height, sc->dev.tex1_c = channels;
     }
     sc->n_textures++;
     return VMX_OK;
@@ -1108,6 +1126,89 @@ int vmx_quantize_device(const void *d_frame_rgbaz, uint64_t npixels, void *d_rgb
     HIP_TRY(hipSetDevice(device));
     LAUNCH_TRY(launch_quantize((const float *)d_frame_rgbaz, npixels, d_rgba8, (float *)d_depth, stream));
     if (!stream) HIP_TRY(hipDeviceSynchronize());
+    return VMX_OK;
+}
+
+} /* extern "C" */
+
+namespace {
+
+// BruteForceTracer::Render (integrators.cpp:9-186) on the device
+int bruteforce_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags, float *d_out,
+                    hipStream_t s, vmx_stats *stats) {
+    const auto t0 = std::chrono::steady_clock::now();
+    vmx_camera c = *cam;
+    if (c.rays_per_pixel == 0 || c.rays_per_pixel > 65535)
+        return fail(VMX_ERR_INVALID, "BruteForceTracer: rays_per_pixel must be 1..65535 (uint16_t sample counter, integrators.cpp:59)");
+    if (flags & ~VMX_BF_ABS_INT) return fail(VMX_ERR_INVALID, "unknown BruteForceTracer flag");
+    const uint32_t spp = c.rays_per_pixel;
+    c.rays_per_pixel = std::max(spp, 4u);  // make_frame's PathTracer-only check (spp/4 strata) does not apply here
+    vmx_opts o = *opts;
+    o.sampling = VMX_SAMPLING_PARITY;
+    FrameDev fr;
+    int rc = make_frame(c, o, fr);
+    if (rc) return rc;
+    fr.spp = spp;
+    Workspace &ws = sc->ws;
+    const uint32_t W = fr.width, rows = fr.local_rows, npix = W * rows;
+    if (npix == 0) {
+        if (stats) std::memset(stats, 0, sizeof(*stats));
+        return VMX_OK;
+    }
+    if (ws.active[0].ensure(npix) || ws.counters.ensure(1)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the render workspace");
+    if (ws.order_w != W || ws.order_rows != rows) {
+        tile_order(W, rows, ws.order);
+        ws.order_w = W, ws.order_rows = rows;
+    }
+    ws.events.reset();
+    std::vector<TimedLaunch> timed;
+    hipEvent_t ev0 = ws.events.get(), ev1 = ws.events.get();
+    if (!ev0 || !ev1) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipMemcpyAsync(ws.active[0].p, ws.order.data(), (size_t)npix * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
+    HIP_TRY(hipEventRecord(ev0, s));
+    LaunchCfg cfg = trace_cfg(sc, (npix + sc->block - 1) / sc->block, 4);
+    TimedLaunch tl{ws.events.get(), ws.events.get(), 0};
+    if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(tl.a, s));
+    LAUNCH_TRY(launch_bruteforce(sc->dev, fr, ws.active[0].p, npix, flags, d_out, ws.counters.p, cfg, s));
+    HIP_TRY(hipEventRecord(tl.b, s));
+    timed.push_back(tl);
+    HIP_TRY(hipEventRecord(ev1, s));
+    return finish_stats(sc, s, timed, ev0, ev1, stats, 1, 1, t0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmx_render_bruteforce_device(const vmx_scene *csc, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
+                                 void *d_out_rgbaz, void *stream, vmx_stats *stats) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (!sc || !cam || !opts || !d_out_rgbaz) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    int rc = bind_device(sc);
+    if (rc) return rc;
+    return bruteforce_impl(sc, cam, opts, flags, (float *)d_out_rgbaz, stream ? (hipStream_t)stream : sc->stream, stats);
+}
+
+int vmx_render_bruteforce(const vmx_scene *csc, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
+                          float *out_rgbaz, vmx_stats *stats) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (!sc || !cam || !opts || !out_rgbaz) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    int rc = bind_device(sc);
+    if (rc) return rc;
+    if (cam->image_res[0] == 0 || cam->image_res[1] == 0) return fail(VMX_ERR_INVALID, "image resolution must be non-zero");
+    if (opts->world > 1 && opts->rank >= opts->world) return fail(VMX_ERR_INVALID, "rank must be < world");
+    const uint32_t rows = local_rows_of(cam->image_res[1], opts->stripe_rows ? opts->stripe_rows : 16u,
+                                        opts->world <= 1 ? 0u : opts->rank, opts->world <= 1 ? 1u : opts->world);
+    const size_t nfloats = (size_t)cam->image_res[0] * rows * 5;
+    if (nfloats == 0) return VMX_OK;
+    if (sc->ws.out.ensure(nfloats)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the frame buffer");
+    rc = bruteforce_impl(sc, cam, opts, flags, sc->ws.out.p, sc->stream, stats);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out_rgbaz, sc->ws.out.p, nfloats * 4, hipMemcpyDeviceToHost));
     return VMX_OK;
 }
 

@@ -72,7 +72,11 @@ struct SceneDev {
     uint32_t ntris;
     // boundTextures[0] (meshEngine.h:62): float[h][w][c] as bindTexture reads it (meshEngine.cpp:74-93)
     const float *tex;
-    uint32_t tex_w, tex_h, tex_c, tex_pad;
+    uint32_t tex_w, tex_h, tex_c;
+    uint32_t tri_off;  // byte offset of `tris` from `inner` (one allocation: unified record fetch of k_trace_w<1>)
+    // boundTextures[1]: BruteForceTracer's albedo (integrators.cpp:141-147)
+    const float *tex1;
+    uint32_t tex1_w, tex1_h, tex1_c, tex1_pad;
 };
 
 // per-stage device counters (one set for depth-0 steps, one for bounce steps)

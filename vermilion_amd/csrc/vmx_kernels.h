@@ -120,6 +120,9 @@ int launch_radiance_init_ids(const float *o, const float *d, uint32_t n, uint64_
 int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,
                    bool pixel_major, const void *rad, PixelStateDev px, unsigned int *next_active,
                    unsigned int *next_count, float *out_rgbaz, DevCounters *counters, void *stream);
+// BruteForceTracer::Render (integrators.cpp:9-186): one lane per pixel of `order` (tile-ordered local pixels)
+int launch_bruteforce(const SceneDev &sc, const FrameDev &fr, const unsigned int *order, uint32_t npix, uint32_t flags,
+                      float *out, DevCounters *counters, LaunchCfg cfg, void *stream);
 int launch_quantize(const float *frame, uint64_t npix, void *rgba8, float *depth, void *stream);
 int launch_assemble(const float *gathered, uint64_t rank_stride_floats, uint32_t width, uint32_t height,
                     uint32_t stripe_rows, uint32_t world, float *frame, void *stream);

@@ -503,19 +503,23 @@ struct StepFlags {
 // returns true if the path continues with a new ray in P, false if accumColour is final
 // VermiTexture::Sample (meshEngine.cpp:21-46): wrap x - floor(x), nearest round(x*(W-1)), 1-4 channels.
 // The texel index is clamped (the reference indexes out of bounds on a NaN uv).
-__device__ __forceinline__ float4 tex_sample(const SceneDev &sc, float u, float v) {
+__device__ __forceinline__ float4 tex_sample_of(const float *tex, uint32_t tex_w, uint32_t tex_h, uint32_t tex_c, float u,
+                                                float v) {
     const float sx = u - floorf(u), sy = v - floorf(v);
-    uint32_t mx = (uint32_t)roundf(sx * (float)(int)(sc.tex_w - 1));
-    uint32_t my = (uint32_t)roundf(sy * (float)(int)(sc.tex_h - 1));
-    mx = min(mx, sc.tex_w - 1);
-    my = min(my, sc.tex_h - 1);
-    const float *p = sc.tex + ((size_t)my * sc.tex_w + mx) * sc.tex_c;
-    switch (sc.tex_c) {
+    uint32_t mx = (uint32_t)roundf(sx * (float)(int)(tex_w - 1));
+    uint32_t my = (uint32_t)roundf(sy * (float)(int)(tex_h - 1));
+    mx = min(mx, tex_w - 1);
+    my = min(my, tex_h - 1);
+    const float *p = tex + ((size_t)my * tex_w + mx) * tex_c;
+    switch (tex_c) {
         case 1: return make_float4(p[0], p[0], p[0], p[0]);
         case 2: return make_float4(p[0], p[1], 0.f, 0.f);
         case 3: return make_float4(p[0], p[1], p[2], 0.f);
         default: return make_float4(p[0], p[1], p[2], p[3]);
     }
+}
+__device__ __forceinline__ float4 tex_sample(const SceneDev &sc, float u, float v) {
+    return tex_sample_of(sc.tex, sc.tex_w, sc.tex_h, sc.tex_c, u, v);
 }
 
 // The loop body is split where the cosine-lobe branch needs cos/sin of r1 (double precision, a few
@@ -2189,6 +2193,118 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
     if (keep) next_active[s_base + my] = lp;
 }
 
+// ---------------------------------------------------------------------------
+// k_bruteforce — BruteForceTracer::Render (core/integrators/integrators.cpp:9-186), the engine's
+// default integrator: one lane per pixel runs the reference's sample loop — jittered camera ray
+// (:65-81), RayCast, N.L against the point light (:83-88), normal perturbation by boundTextures[0]
+// (:98-106), the mirror probe (:119-137), albedo (:141-156), the convergence break (:166-172) —
+// and writes the pixel (:176-183).  Lanes are dealt 8x8-pixel tiles (the active list), so a wave's
+// rays are coherent; the break makes most pixels stop after 3 samples.  Jitters come from the
+// stream keyed (seed, pixel, sample) (the reference shares one unsynchronised std::mt19937, :30).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_bruteforce(SceneDev sc, FrameDev fr, const unsigned int *__restrict__ order, uint32_t npix, uint32_t flags,
+             float *__restrict__ out, DevCounters *ctr) {
+    extern __shared__ uint2 lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    Cnt cnt = {0, 0};
+    uint32_t n_prim = 0, n_sec = 0, n_hits = 0, n_samples = 0;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < npix; base += gridDim.x * blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        if (i >= npix) continue;
+        const uint32_t lp = order[i];
+        const uint32_t p = global_pixel(fr, lp);
+        float hitDistance = 0.f;
+        float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;      // accum
+        float lx = 0.f, ly = 0.f, lz = 0.f, lw = 0.f;      // lastSampleColour
+        float cx = 0.f, cy = 0.f, cz = 0.f, cw = 0.f;      // currentSampleColour
+        uint32_t n = 0;
+        for (uint32_t sample = 0; sample < fr.spp; ++sample) {  // :59
+            ++n;
+            Rng rng;
+            rng_init(rng, fr.seed, p, sample);
+            const float jx = rng_jitter(rng), jy = rng_jitter(rng);
+            const float hX = (float)((((double)((float)(p % fr.width) + jx) - 0.25) / (double)fr.width) * 2.0 - 1.0);   // :65
+            const float hY = (float)((((double)((float)(p / fr.width) + jy) - 0.25) / (double)fr.height) * 2.0 - 1.0);  // :66
+            const float bx = (float)((double)(hX * fr.sensor_x) * 0.5), by = (float)((double)(hY * fr.sensor_y) * 0.5);  // :73-74
+            const float gx = bx, gy = -by, gz = -fr.film_dist;  // :76
+            float dx = (fr.m[0] * gx + fr.m[3] * gy) + (fr.m[6] * gz + 0.0f);  // :79, GLM mat4*vec4 order
+            float dy = (fr.m[1] * gx + fr.m[4] * gy) + (fr.m[7] * gz + 0.0f);
+            float dz = (fr.m[2] * gx + fr.m[5] * gy) + (fr.m[8] * gz + 0.0f);
+            normalize3(dx, dy, dz);  // :81 (w == 1)
+            ++n_prim;
+            CastResult c;
+            ray_cast<false>(sc, fr.px, fr.py, fr.pz, dx, dy, dz, stk, c, cnt);
+            hitDistance = c.nearest;  // *pHitDistance (meshEngine.cpp:507)
+            if (c.nearest < kInf) {
+                if (c.slot >= 0) ++n_hits;
+                const float hx = fr.px + (dx * c.nearest), hy = fr.py + (dy * c.nearest), hz = fr.pz + (dz * c.nearest);
+                float nx = c.nx, ny = c.ny, nz = c.nz;
+                float Lx = 500.f - hx, Ly = 1100.f - hy, Lz = 2000.f - hz;  // :16,83
+                normalize3(Lx, Ly, Lz);                                     // :84
+                float unx = nx, uny = ny, unz = nz;
+                normalize3(unx, uny, unz);
+                float vNDL = dot3(Lx, Ly, Lz, unx, uny, unz);  // :88
+                if (sc.tex) {                                   // :98-106
+                    const float4 t = tex_sample(sc, c.uvx, c.uvy);
+                    nx = nx + t.x, ny = ny + t.y, nz = nz + t.z;
+                    unx = nx, uny = ny, unz = nz;
+                    normalize3(unx, uny, unz);
+                    vNDL = dot3(Lx, Ly, Lz, unx, uny, unz);
+                }
+                // :119  -L - 2.f * N * dot(N, -L)
+                const float mLx = -Lx, mLy = -Ly, mLz = -Lz;
+                const float k = dot3(nx, ny, nz, mLx, mLy, mLz);
+                const float sx = mLx - (2.f * nx) * k, sy = mLy - (2.f * ny) * k, sz = mLz - (2.f * nz) * k;
+                if (finite3(sx, sy, sz)) ++n_sec;
+                CastResult c2;
+                ray_cast<false>(sc, hx, hy, hz, sx, sy, sz, stk, c2, cnt);  // :121
+                if (!(c2.nearest < kInf)) {                                  // :133-137
+                    vNDL = vNDL * 0.9f;
+                    vNDL = vNDL + 0.1f;
+                }
+                if (sc.tex1) {  // :141-147
+                    const float4 t = tex_sample_of(sc.tex1, sc.tex1_w, sc.tex1_h, sc.tex1_c, c.uvx, c.uvy);
+                    cx = t.x * vNDL, cy = t.y * vNDL, cz = t.z * vNDL, cw = 1.0f;
+                } else {  // :148-156
+                    cx = 0.890196078f * vNDL, cy = 0.258823529f * vNDL, cz = 0.203921569f * vNDL, cw = 1.0f;
+                }
+                ax = ax + cx, ay = ay + cy, az = az + cz, aw = aw + cw;  // :158
+            }
+            const float fn = (float)n;
+            if (n > 2) {  // :167-172
+                lx = lx - ax / fn, ly = ly - ay / fn, lz = lz - az / fn, lw = lw - aw / fn;
+                const float sum = ((lx + ly) + lz) + lw;
+                float mag;
+                if (flags & 1u) {  // VMX_BF_ABS_INT: abs(int), the float truncated to int first
+                    const double tr = trunc((double)sum);
+                    mag = (tr >= -2147483648.0 && tr <= 2147483647.0) ? (float)abs((int)tr) : 0.f;
+                } else {
+                    mag = fabsf(sum);
+                }
+                if (mag < 0.001f) break;
+            }
+            lx = ax / fn, ly = ay / fn, lz = az / fn, lw = aw / fn;  // :173
+        }
+        n_samples += n;
+        const float fn = (float)n;
+        float *o5 = out + (size_t)lp * 5;  // :176-183
+        o5[0] = sel_max(sel_min(ax / fn, 1.f), 0.f);  // std::max(std::min(x, 1.f), 0.f), NaN and all
+        o5[1] = sel_max(sel_min(ay / fn, 1.f), 0.f);
+        o5[2] = sel_max(sel_min(az / fn, 1.f), 0.f);
+        o5[3] = aw / fn;
+        o5[4] = hitDistance;
+    }
+    const uint32_t wp = wave_sum(n_prim), ws = wave_sum(n_sec), wh = wave_sum(n_hits), wn = wave_sum(n_samples);
+    if (lane == 0) {
+        if (wp) atomicAdd(&ctr->stage[0].rays, (unsigned long long)wp);
+        if (ws) atomicAdd(&ctr->stage[1].rays, (unsigned long long)ws);
+        if (wh) atomicAdd(&ctr->stage[0].tri_hits, (unsigned long long)wh);
+        if (wn) atomicAdd(&ctr->samples, (unsigned long long)wn);
+    }
+}
+
 __global__ void k_assemble(const float *__restrict__ gathered, uint64_t rank_stride, uint32_t width,
                            uint32_t height, uint32_t stripe_rows, uint32_t world, float *__restrict__ frame) {
     const uint64_t total = (uint64_t)width * height * 5;
@@ -2443,6 +2559,13 @@ int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_ac
     hipLaunchKernelGGL(k_resolve, dim3((n_active + 255) / 256), dim3(256), 0, (hipStream_t)stream, fr, active,
                        n_active, n_pad, samples, pixel_major ? 1u : 0u, (const float4 *)rad, px, next_active,
                        next_count, out_rgbaz, counters);
+    return launch_status();
+}
+
+int launch_bruteforce(const SceneDev &sc, const FrameDev &fr, const unsigned int *order, uint32_t npix, uint32_t flags,
+                      float *out, DevCounters *counters, LaunchCfg cfg, void *stream) {
+    hipLaunchKernelGGL(k_bruteforce, dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, (hipStream_t)stream, sc, fr, order,
+                       npix, flags, out, counters);
     return launch_status();
 }
 

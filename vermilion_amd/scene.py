@@ -178,6 +178,16 @@ class Scene:
         L.check(L.lib().vmx_render(self._h, C.byref(cam), C.byref(opts), out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
 
+    def render_bruteforce(self, cam, opts, flags=0):
+        """BruteForceTracer::Render (core/integrators/integrators.cpp:9-186) into a host array
+        [local_rows, W, 5]: r, g, b, alpha = hit fraction, depth = last sample's hit distance."""
+        rows = local_rows(cam.image_res[1], opts.stripe_rows, opts.rank, opts.world)
+        out = np.empty((rows, cam.image_res[0], 5), np.float32)
+        st = L.Stats()
+        L.check(L.lib().vmx_render_bruteforce(self._h, C.byref(cam), C.byref(opts), int(flags), out.ctypes.data,
+                                              C.byref(st)))
+        return out, st.as_dict()
+
     def render_device(self, cam, opts, d_out_ptr, stream_ptr=None):
         """Same, into device memory (e.g. a torch tensor's data_ptr()) on `stream_ptr`."""
         st = L.Stats()
