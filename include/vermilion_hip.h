@@ -253,6 +253,31 @@ int vmx_assemble_device(const void *d_gathered, uint64_t rank_stride_floats, uin
                         uint32_t height, uint32_t stripe_rows, uint32_t world, void *d_frame,
                         int device, void *stream);
 
+/* ---- multi-device render in one process ---------------------------------------------------
+ * Vermilion's main.cpp (main.cpp:58-104) is ONE process; these entry points let its Integrator use
+ * every GPU of the node: the scene is replicated on each device of the list (one host-side BVH build,
+ * one upload per device), every replica renders its interleaved stripes of `stripe_rows` rows
+ * (vmx_opts.rank/world are set by the library; the RNG is keyed by the global pixel, so the frame does
+ * not depend on the device count), the packed stripes are pushed device-to-device into a gather buffer
+ * on devices[0] (peer copies over xGMI — each peer has its own link to the root, no ring) and
+ * de-interleaved there.  A device may appear more than once in the list (rehearsal of the N-rank path
+ * on fewer GPUs).  The result is bit-identical to vmx_render on one device.
+ */
+typedef struct vmx_multi vmx_multi;
+int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32_t ntris, const vmx_sphere *spheres,
+                     uint32_t nspheres, uint32_t leaf_size, uint32_t builder, const int *devices, uint32_t ndevices,
+                     vmx_multi **out);
+int vmx_multi_destroy(vmx_multi *m);
+uint32_t vmx_multi_world(const vmx_multi *m);
+int vmx_multi_bind_texture(vmx_multi *m, const float *data, uint32_t width, uint32_t height, uint32_t channels);
+/* whole frame (W*H*5 floats) into a caller-owned HOST buffer / into DEVICE memory on devices[0];
+ * stats: rays and samples summed over the devices, times = the slowest device's */
+int vmx_multi_render(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, float *out_rgbaz, vmx_stats *stats);
+int vmx_multi_render_device(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, void *d_out_rgbaz,
+                            vmx_stats *stats);
+int vmx_multi_render_bruteforce(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
+                                float *out_rgbaz, vmx_stats *stats);
+
 /* ---- BruteForceTracer: the engine's DEFAULT integrator --------------------
  * Replaces Vermilion::BruteForceTracer::Render (core/integrators/integrators.cpp:9-186; installed by
  * RenderEngine::Initialise when no integrator is assigned, core/engines/renderEngine.cpp:49-53):

@@ -84,6 +84,14 @@ def test_argument_errors_do_not_need_a_gpu(hip_lib):
     assert hip_lib.vmx_local_rows(100, 16, 5, 4, C.byref(r)) == L.VMX_ERR_INVALID
     assert hip_lib.vmx_render(None, None, None, None, None) == L.VMX_ERR_INVALID
     assert hip_lib.vmx_scene_destroy(None) == L.VMX_OK
+    # BruteForceTracer and the multi-device entry points follow the same convention
+    assert hip_lib.vmx_render_bruteforce(None, None, None, 0, None, None) == L.VMX_ERR_INVALID
+    assert hip_lib.vmx_multi_render(None, None, None, None, None) == L.VMX_ERR_INVALID
+    assert hip_lib.vmx_multi_destroy(None) == L.VMX_OK and hip_lib.vmx_multi_world(None) == 0
+    m = C.c_void_p()
+    devs = (C.c_int * 2)(0, 1)
+    assert hip_lib.vmx_multi_create(pos.ctypes.data, pos.ctypes.data, None, 1, None, 0, 4, 0, devs, 0, C.byref(m)) == L.VMX_ERR_INVALID
+    assert hip_lib.vmx_multi_create(pos.ctypes.data, pos.ctypes.data, None, 1, None, 0, 4, 0, None, 2, C.byref(m)) == L.VMX_ERR_INVALID
 
 
 def test_no_device_fails_loudly(hip_lib):
@@ -98,6 +106,9 @@ def test_no_device_fails_loudly(hip_lib):
     import vermilion_amd as va
     with pytest.raises(va.VmxError):
         va.Scene(pos, pos)
+    with pytest.raises(va.VmxError) as e:
+        va.MultiScene(pos, pos, devices=[0, 1])
+    assert e.value.code == L.VMX_ERR_NO_DEVICE
 
 
 def test_local_rows_matches_host_logic(hip_lib):

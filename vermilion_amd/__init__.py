@@ -7,14 +7,14 @@ Importing `vermilion_amd` does not need a GPU; creating a Scene does.
 """
 from . import _lib
 from ._lib import (VMX_SAMPLING_CORRECTED, VMX_SAMPLING_PARITY, VmxError)
-from .scene import (Scene, default_spheres, local_row_indices, local_rows, make_camera, make_opts,
+from .scene import (MultiScene, Scene, default_spheres, local_row_indices, local_rows, make_camera, make_opts,
                     spheres_array)
 from .api import (Camera, Integrator, MeshEngine, PathTracer, RenderEngine, cameraSettings, float3,
                   pixelValue, vermRenderMode)
 from . import scenes
 
 __all__ = [
-    "Scene", "make_camera", "make_opts", "spheres_array", "default_spheres", "local_rows",
+    "Scene", "MultiScene", "make_camera", "make_opts", "spheres_array", "default_spheres", "local_rows",
     "local_row_indices", "Camera", "Integrator", "MeshEngine", "PathTracer", "RenderEngine",
     "cameraSettings", "float3", "pixelValue", "vermRenderMode", "scenes", "VmxError",
     "VMX_SAMPLING_PARITY", "VMX_SAMPLING_CORRECTED",

@@ -154,6 +154,15 @@ SYMBOLS = {
     "vmx_render_bruteforce": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), C.c_uint32, _P, C.POINTER(Stats)]),
     "vmx_render_bruteforce_device": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), C.c_uint32, _P, _P,
                                               C.POINTER(Stats)]),
+    "vmx_multi_create": (C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_int),
+                                  C.c_uint32, C.POINTER(_P)]),
+    "vmx_multi_destroy": (C.c_int, [_P]),
+    "vmx_multi_world": (C.c_uint32, [_P]),
+    "vmx_multi_bind_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "vmx_multi_render": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),
+    "vmx_multi_render_device": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),
+    "vmx_multi_render_bruteforce": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), C.c_uint32, _P,
+                                             C.POINTER(Stats)]),
     "vmx_quantize_device": (C.c_int, [_P, C.c_uint64, _P, _P, C.c_int, _P]),
     "vmx_assemble_device": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, C.c_int, _P]),
 }

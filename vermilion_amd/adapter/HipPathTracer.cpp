@@ -8,7 +8,10 @@
 
 namespace Vermilion {
 
-HipIntegratorBase::~HipIntegratorBase() { vmx_scene_destroy(mScene); }
+HipIntegratorBase::~HipIntegratorBase() {
+    vmx_scene_destroy(mScene);
+    vmx_multi_destroy(mMulti);
+}
 
 // Flatten MeshEngine::sceneMeshes exactly as MeshEngine::createBVH does
 // (core/engines/meshEngine.cpp:660-718): mesh-major, face-minor; that push
@@ -18,7 +21,8 @@ bool HipIntegratorBase::upload(MeshEngine *mEng) {
     std::vector<float> pos, nrm, uv;
     size_t faces = 0;
     for (aiMesh *mesh : mEng->sceneMeshes) faces += mesh->mNumFaces;
-    if (mScene && mUploadedFrom == mEng && mUploadedFaces == faces && mUploadedTextures == mEng->boundTextures.size())
+    if ((mScene || mMulti) && mUploadedFrom == mEng && mUploadedFaces == faces &&
+        mUploadedTextures == mEng->boundTextures.size())
         return true;
     pos.reserve(faces * 9), nrm.reserve(faces * 9), uv.reserve(faces * 6);
     for (aiMesh *mesh : mEng->sceneMeshes) {
@@ -39,23 +43,36 @@ bool HipIntegratorBase::upload(MeshEngine *mEng) {
         }
     }
     vmx_scene_destroy(mScene);
-    mScene = nullptr;
+    vmx_multi_destroy(mMulti);
+    mScene = nullptr, mMulti = nullptr;
     // NULL,0 -> the reference's eight hard-coded spheres (meshEngine.cpp:377-500); leaf size 4 (bvh.h:29)
-    if (vmx_scene_create(pos.data(), nrm.data(), uv.data(), (uint32_t)faces, nullptr, 0, 4, mDevice, &mScene) != VMX_OK) {
-        std::fprintf(stderr, "HipPathTracer: %s\n", vmx_last_error());
+    const int rc = mDevices.size() > 1
+                       ? vmx_multi_create(pos.data(), nrm.data(), uv.data(), (uint32_t)faces, nullptr, 0, 4, VMX_BVH_REFERENCE,
+                                          mDevices.data(), (uint32_t)mDevices.size(), &mMulti)
+                       : vmx_scene_create(pos.data(), nrm.data(), uv.data(), (uint32_t)faces, nullptr, 0, 4, mDevices[0], &mScene);
+    if (rc != VMX_OK) {
+        std::fprintf(stderr, "vermilion_hip: %s\n", vmx_last_error());
         return false;
     }
     // boundTextures[0] is the only texture Radiance samples (pathtracer.cpp:63-66); BruteForceTracer also
     // reads boundTextures[1] (integrators.cpp:141-147).  Bound in order, as MeshEngine::bindTexture appends.
     for (size_t t = 0; t < mEng->boundTextures.size() && t < 2; ++t) {
         const VermiTexture &tx = mEng->boundTextures[t];
-        if (vmx_scene_bind_texture(mScene, tx.pData, tx.nWidth, tx.nHeight, tx.nChannels) != VMX_OK)
+        if ((mMulti ? vmx_multi_bind_texture(mMulti, tx.pData, tx.nWidth, tx.nHeight, tx.nChannels)
+                    : vmx_scene_bind_texture(mScene, tx.pData, tx.nWidth, tx.nHeight, tx.nChannels)) != VMX_OK)
             std::fprintf(stderr, "vermilion_hip: %s\n", vmx_last_error());
     }
     mUploadedFrom = mEng;
     mUploadedFaces = faces;
     mUploadedTextures = mEng->boundTextures.size();
     return true;
+}
+
+int HipIntegratorBase::renderFrame(const vmx_camera &c, const vmx_opts &o, bool bruteForce, uint32_t flags, float *frame,
+                                   vmx_stats *st) {
+    if (mMulti)
+        return bruteForce ? vmx_multi_render_bruteforce(mMulti, &c, &o, flags, frame, st) : vmx_multi_render(mMulti, &c, &o, frame, st);
+    return bruteForce ? vmx_render_bruteforce(mScene, &c, &o, flags, frame, st) : vmx_render(mScene, &c, &o, frame, st);
 }
 
 vmx_camera HipIntegratorBase::describe(const Camera *cam) {
@@ -94,7 +111,7 @@ void HipPathTracer::Render(std::vector<Vermilion::Camera *> &cameraList, MeshEng
         o.sampling = VMX_SAMPLING_PARITY;    // r2 = 10*U, pathtracer.cpp:156
         std::vector<float> frame((size_t)cam->RenderTargetSize * 5);
         vmx_stats st;
-        if (vmx_render(mScene, &c, &o, frame.data(), &st) != VMX_OK) {
+        if (renderFrame(c, o, false, 0, frame.data(), &st) != VMX_OK) {
             std::fprintf(stderr, "HipPathTracer: %s\n", vmx_last_error());
             continue;
         }
@@ -112,7 +129,7 @@ void HipBruteForceTracer::Render(std::vector<Vermilion::Camera *> &cameraList, M
         o.seed = mSeed;
         std::vector<float> frame((size_t)cam->RenderTargetSize * 5);
         vmx_stats st;
-        if (vmx_render_bruteforce(mScene, &c, &o, mFlags, frame.data(), &st) != VMX_OK) {
+        if (renderFrame(c, o, true, mFlags, frame.data(), &st) != VMX_OK) {
             std::fprintf(stderr, "HipBruteForceTracer: %s\n", vmx_last_error());
             continue;
         }

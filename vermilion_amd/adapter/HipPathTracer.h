@@ -9,7 +9,12 @@
 // core/integrators/pathtracer.cpp:200-328).  Installed exactly like it:
 //     auto integrator = new Vermilion::HipPathTracer();   // main.cpp:61
 //     rEng->assignIntegrator(integrator);                 // main.cpp:63
+// or, for every GPU of the node from the one process main.cpp is:
+//     auto integrator = new Vermilion::HipPathTracer(/*seed=*/1, std::vector<int>{0, 1, 2, 3, 4, 5, 6, 7});
 #pragma once
+#include <utility>
+#include <vector>
+
 #include "integrators/integrators.h"  // Vermilion::Integrator, Camera, MeshEngine
 #include "vermilion_hip.h"
 
@@ -20,23 +25,30 @@ namespace Vermilion {
 class HipIntegratorBase : public Integrator {
    public:
     // seed: the reference seeds from std::random_device (pathtracer.cpp:231) / time(0) (integrators.cpp:30)
-    explicit HipIntegratorBase(uint64_t seed, int device) : mSeed(seed), mDevice(device) {}
+    explicit HipIntegratorBase(uint64_t seed, std::vector<int> devices) : mSeed(seed), mDevices(std::move(devices)) {
+        if (mDevices.empty()) mDevices.push_back(0);
+    }
     ~HipIntegratorBase() override;
 
    protected:
     bool upload(MeshEngine *mEng);
     static vmx_camera describe(const Camera *cam);
     static void writeBack(Camera *cam, const std::vector<float> &frame);
+    // one frame through the library: the whole node when several devices were listed (vmx_multi_*:
+    // one process, stripes sharded over the devices, gathered over xGMI on the first), else one device
+    int renderFrame(const vmx_camera &c, const vmx_opts &o, bool bruteForce, uint32_t flags, float *frame, vmx_stats *st);
     uint64_t mSeed;
-    int mDevice;
-    vmx_scene *mScene = nullptr;
+    std::vector<int> mDevices;
+    vmx_scene *mScene = nullptr;   // one device
+    vmx_multi *mMulti = nullptr;   // several
     const MeshEngine *mUploadedFrom = nullptr;
     size_t mUploadedFaces = 0, mUploadedTextures = 0;
 };
 
 class HipPathTracer : public HipIntegratorBase {
    public:
-    explicit HipPathTracer(uint64_t seed = 1, int device = 0) : HipIntegratorBase(seed, device) {}
+    explicit HipPathTracer(uint64_t seed = 1, int device = 0) : HipIntegratorBase(seed, {device}) {}
+    HipPathTracer(uint64_t seed, std::vector<int> devices) : HipIntegratorBase(seed, std::move(devices)) {}
     void Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) override;
 };
 
@@ -47,7 +59,9 @@ class HipBruteForceTracer : public HipIntegratorBase {
    public:
     // absAsInt: read the unqualified abs() of integrators.cpp:170 as C's abs(int) (VMX_BF_ABS_INT)
     explicit HipBruteForceTracer(uint64_t seed = 1, int device = 0, bool absAsInt = false)
-        : HipIntegratorBase(seed, device), mFlags(absAsInt ? VMX_BF_ABS_INT : 0u) {}
+        : HipIntegratorBase(seed, {device}), mFlags(absAsInt ? VMX_BF_ABS_INT : 0u) {}
+    HipBruteForceTracer(uint64_t seed, std::vector<int> devices, bool absAsInt = false)
+        : HipIntegratorBase(seed, std::move(devices)), mFlags(absAsInt ? VMX_BF_ABS_INT : 0u) {}
     void Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) override;
 
    private:

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.h"
@@ -758,6 +759,56 @@ int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32
     return vmx_scene_create_ex(pos, nrm, uv, ntris, spheres, nspheres, leaf_size, VMX_BVH_REFERENCE, device, out);
 }
 
+// device half of scene creation: uploads sc->bvh / sc->spheres to sc->device (used for the first scene
+// and for the replicas of a multi-device scene, which share one host-side build)
+static int scene_upload(vmx_scene *sc) {
+    const int device = sc->device;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    sc->num_cus = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+
+    std::vector<SphereDev> sd(sc->spheres.size());
+    for (size_t i = 0; i < sd.size(); ++i) {
+        const vmx_sphere &s = sc->spheres[i];
+        SphereDev &d = sd[i];
+        std::memset(&d, 0, sizeof(d));
+        d.cx = s.centre[0], d.cy = s.centre[1], d.cz = s.centre[2];
+        d.rad = s.radius;
+        d.rad2 = s.radius * s.radius;  // float product (meshEngine.cpp:188)
+        d.colr = s.colour[0], d.colg = s.colour[1], d.colb = s.colour[2];
+        d.ncx = s.normal_centre[0], d.ncy = s.normal_centre[1], d.ncz = s.normal_centre[2];
+        d.nsign = s.normal_sign < 0.f ? -1.f : 1.f;
+        d.flags = s.flags;
+    }
+    const HostBvh &b = sc->bvh;
+    const size_t inner_bytes = std::max<size_t>(b.inner.size(), 1) * sizeof(InnerRecord);
+    const size_t tri_bytes = b.tris.size() * sizeof(TriRecord);
+    if (inner_bytes + tri_bytes + 64 > 0xFFFFFFFFull) return fail(VMX_ERR_INVALID, "scene too large for 32-bit record offsets");
+    if (sc->d_geom.ensure(inner_bytes + tri_bytes + 64) ||
+        sc->d_attrs.ensure(b.attrs.size()) || sc->d_spheres.ensure(std::max<size_t>(sd.size(), 1)))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the scene");
+    HIP_TRY(hipMemset(sc->d_geom.p, 0, inner_bytes + tri_bytes + 64));
+    if (b.inner.size()) HIP_TRY(hipMemcpy(sc->d_geom.p, b.inner.data(), b.inner.size() * sizeof(InnerRecord), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->d_geom.p + inner_bytes, b.tris.data(), tri_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sc->d_attrs.p, b.attrs.data(), b.attrs.size() * sizeof(AttrRecord), hipMemcpyHostToDevice));
+    if (sd.size()) HIP_TRY(hipMemcpy(sc->d_spheres.p, sd.data(), sd.size() * sizeof(SphereDev), hipMemcpyHostToDevice));
+    sc->dev.inner = sc->d_geom.p;
+    sc->dev.tris = sc->d_geom.p + inner_bytes;
+    sc->dev.tri_off = (uint32_t)inner_bytes;
+    sc->dev.attrs = sc->d_attrs.p;
+    sc->dev.spheres = sc->d_spheres.p;
+    sc->dev.root_ref = b.root_ref;
+    sc->dev.nspheres = (uint32_t)sd.size();
+    sc->dev.stack_entries = b.max_depth + 2;
+    sc->dev.ntris = sc->ntris;
+    // LDS budget: shrink the block until one block's stacks fit in 64 KiB
+    sc->block = 256;
+    while (sc->block > 64 && (sc->block / 64) * sc->dev.stack_entries * 512 > 65536) sc->block /= 2;
+    return VMX_OK;
+}
+
 int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                         const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size, uint32_t builder,
                         int device, vmx_scene **out) {
@@ -790,61 +841,12 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
         sc->spheres.assign(spheres, spheres + nspheres);
     else
         sc->spheres.assign(kReferenceSpheres, kReferenceSpheres + 8);
-
-    auto bail = [&](int code, const std::string &m) {
+    const int rc = scene_upload(sc);
+    if (rc) {
+        const std::string keep = g_err;
         vmx_scene_destroy(sc);
-        return fail(code, m);
-    };
-    if (hipSetDevice(device) != hipSuccess) return bail(VMX_ERR_HIP, "hipSetDevice failed");
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(VMX_ERR_HIP, "hipGetDeviceProperties");
-    sc->num_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking) != hipSuccess)
-        return bail(VMX_ERR_HIP, "hipStreamCreate failed");
-
-    std::vector<SphereDev> sd(sc->spheres.size());
-    for (size_t i = 0; i < sd.size(); ++i) {
-        const vmx_sphere &s = sc->spheres[i];
-        SphereDev &d = sd[i];
-        std::memset(&d, 0, sizeof(d));
-        d.cx = s.centre[0], d.cy = s.centre[1], d.cz = s.centre[2];
-        d.rad = s.radius;
-        d.rad2 = s.radius * s.radius;  // float product (meshEngine.cpp:188)
-        d.colr = s.colour[0], d.colg = s.colour[1], d.colb = s.colour[2];
-        d.ncx = s.normal_centre[0], d.ncy = s.normal_centre[1], d.ncz = s.normal_centre[2];
-        d.nsign = s.normal_sign < 0.f ? -1.f : 1.f;
-        d.flags = s.flags;
+        return fail(rc, keep);
     }
-    const HostBvh &b = sc->bvh;
-    const size_t inner_bytes = std::max<size_t>(b.inner.size(), 1) * sizeof(InnerRecord);
-    const size_t tri_bytes = b.tris.size() * sizeof(TriRecord);
-    // + 64: the unified fetch reads 56 bytes from a 48-byte triangle record's start
-    if (inner_bytes + tri_bytes + 64 > 0xFFFFFFFFull) return bail(VMX_ERR_INVALID, "scene too large for 32-bit record offsets");
-    if (sc->d_geom.ensure(inner_bytes + tri_bytes + 64) ||
-        sc->d_attrs.ensure(b.attrs.size()) || sc->d_spheres.ensure(std::max<size_t>(sd.size(), 1)))
-        return bail(VMX_ERR_NOMEM, "hipMalloc failed for the scene");
-    if (hipMemset(sc->d_geom.p, 0, inner_bytes + tri_bytes + 64) != hipSuccess) return bail(VMX_ERR_HIP, "hipMemset failed");
-    if ((b.inner.size() && hipMemcpy(sc->d_geom.p, b.inner.data(), b.inner.size() * sizeof(InnerRecord),
-                                     hipMemcpyHostToDevice) != hipSuccess) ||
-        hipMemcpy(sc->d_geom.p + inner_bytes, b.tris.data(), tri_bytes, hipMemcpyHostToDevice) !=
-            hipSuccess ||
-        hipMemcpy(sc->d_attrs.p, b.attrs.data(), b.attrs.size() * sizeof(AttrRecord), hipMemcpyHostToDevice) !=
-            hipSuccess ||
-        (sd.size() && hipMemcpy(sc->d_spheres.p, sd.data(), sd.size() * sizeof(SphereDev),
-                                hipMemcpyHostToDevice) != hipSuccess))
-        return bail(VMX_ERR_HIP, "scene upload failed");
-    sc->dev.inner = sc->d_geom.p;
-    sc->dev.tris = sc->d_geom.p + inner_bytes;
-    sc->dev.tri_off = (uint32_t)inner_bytes;
-    sc->dev.attrs = sc->d_attrs.p;
-    sc->dev.spheres = sc->d_spheres.p;
-    sc->dev.root_ref = b.root_ref;
-    sc->dev.nspheres = (uint32_t)sd.size();
-    sc->dev.stack_entries = b.max_depth + 2;
-    sc->dev.ntris = ntris;
-    // LDS budget: shrink the block until one block's stacks fit in 64 KiB
-    sc->block = 256;
-    while (sc->block > 64 && (sc->block / 64) * sc->dev.stack_entries * 512 > 65536) sc->block /= 2;
     *out = sc;
     return VMX_OK;
 }
@@ -1210,6 +1212,198 @@ int vmx_render_bruteforce(const vmx_scene *csc, const vmx_camera *cam, const vmx
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out_rgbaz, sc->ws.out.p, nfloats * 4, hipMemcpyDeviceToHost));
     return VMX_OK;
+}
+
+} /* extern "C" */
+
+// ---------------------------------------------------------------------------
+// multi-device rendering in ONE process (north_star: "tiles shard across the 8 GPUs of one node with a
+// gather of per-tile framebuffers over xGMI"): a Vermilion main.cpp is a single process, so the
+// sharding must be reachable from the C ABI, not only from one-process-per-GPU launchers.
+// ---------------------------------------------------------------------------
+struct vmx_multi {
+    std::vector<vmx_scene *> replica;  // one scene replica per entry of the device list (entries may repeat)
+    DevBuf<float> gathered, frame;     // on the root = replica[0]'s device
+    std::mutex mu;
+};
+
+namespace {
+
+template <class RenderFn>
+int multi_render(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, float *out_host, void *d_out_root,
+                 vmx_stats *stats, RenderFn render_one) {
+    const uint32_t world = (uint32_t)m->replica.size();
+    const uint32_t W = cam->image_res[0], H = cam->image_res[1];
+    if (W == 0 || H == 0) return fail(VMX_ERR_INVALID, "image resolution must be non-zero");
+    const uint32_t stripe = opts->stripe_rows ? opts->stripe_rows : 16u;
+    uint32_t max_rows = 0;
+    for (uint32_t r = 0; r < world; ++r) max_rows = std::max(max_rows, local_rows_of(H, stripe, r, world));
+    const uint64_t stride = (uint64_t)max_rows * W * 5;  // floats per rank slot of the gather buffer
+    vmx_scene *root = m->replica[0];
+    HIP_TRY(hipSetDevice(root->device));
+    if (m->gathered.ensure((size_t)stride * world) || m->frame.ensure((size_t)W * H * 5))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the gather buffer");
+
+    // one host thread per replica: render its interleaved stripes into its own device buffer, then push
+    // them into the root's gather buffer — a device-to-device copy (peer copy over xGMI when the replica
+    // sits on another GPU: every peer has its own link to the root; not a ring)
+    std::vector<int> rc(world, VMX_OK);
+    std::vector<std::string> msg(world);
+    std::vector<vmx_stats> st(world);
+    std::vector<std::thread> th;
+    for (uint32_t r = 0; r < world; ++r) {
+        th.emplace_back([&, r]() {
+            vmx_scene *sc = m->replica[r];
+            vmx_opts o = *opts;
+            o.rank = r, o.world = world, o.stripe_rows = stripe;
+            std::lock_guard<std::mutex> lock(sc->mu);
+            auto body = [&]() -> int {
+                int e = bind_device(sc);
+                if (e) return e;
+                const size_t nfloats = (size_t)local_rows_of(H, stripe, r, world) * W * 5;
+                if (nfloats == 0) return VMX_OK;
+                if (sc->ws.out.ensure(nfloats)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the frame buffer");
+                e = render_one(sc, &o, sc->ws.out.p, &st[r]);
+                if (e) return e;
+                HIP_TRY(hipMemcpyPeerAsync(m->gathered.p + (size_t)stride * r, root->device, sc->ws.out.p, sc->device,
+                                           nfloats * 4, sc->stream));
+                HIP_TRY(hipStreamSynchronize(sc->stream));
+                return VMX_OK;
+            };
+            std::memset(&st[r], 0, sizeof(vmx_stats));
+            rc[r] = body();
+            if (rc[r]) msg[r] = g_err;  // g_err is thread-local
+        });
+    }
+    for (auto &t : th) t.join();
+    for (uint32_t r = 0; r < world; ++r)
+        if (rc[r]) return fail(rc[r], "device " + std::to_string(m->replica[r]->device) + ": " + msg[r]);
+
+    HIP_TRY(hipSetDevice(root->device));
+    float *d_frame = d_out_root ? (float *)d_out_root : m->frame.p;
+    LAUNCH_TRY(launch_assemble(m->gathered.p, stride, W, H, stripe, world, d_frame, root->stream));
+    if (out_host) HIP_TRY(hipMemcpyAsync(out_host, d_frame, (size_t)W * H * 5 * 4, hipMemcpyDeviceToHost, root->stream));
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (uint32_t r = 0; r < world; ++r) {
+            const vmx_stats &a = st[r];
+            stats->rays_primary += a.rays_primary, stats->rays_secondary += a.rays_secondary;
+            stats->samples += a.samples, stats->samples_discarded += a.samples_discarded;
+            stats->kernel_launches += a.kernel_launches;
+            stats->passes = std::max(stats->passes, a.passes);
+            stats->ms_total = std::max(stats->ms_total, a.ms_total);     // ranks run side by side: the slowest one
+            stats->ms_device = std::max(stats->ms_device, a.ms_device);
+            vmx_stage_stats *dst[3] = {&stats->primary, &stats->bounce, &stats->shade};
+            const vmx_stage_stats *src[3] = {&a.primary, &a.bounce, &a.shade};
+            for (int k = 0; k < 3; ++k) {
+                dst[k]->rays += src[k]->rays, dst[k]->inner_visits += src[k]->inner_visits;
+                dst[k]->tri_tests += src[k]->tri_tests, dst[k]->tri_hits += src[k]->tri_hits;
+                dst[k]->continued += src[k]->continued, dst[k]->launches += src[k]->launches;
+                dst[k]->ms = std::max(dst[k]->ms, src[k]->ms);
+            }
+        }
+    }
+    return VMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32_t ntris, const vmx_sphere *spheres,
+                     uint32_t nspheres, uint32_t leaf_size, uint32_t builder, const int *devices, uint32_t ndevices,
+                     vmx_multi **out) {
+    if (!out) return fail(VMX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!devices || ndevices == 0 || ndevices > 64) return fail(VMX_ERR_INVALID, "device list must hold 1..64 entries");
+    vmx_scene *first = nullptr;
+    int rc = vmx_scene_create_ex(pos, nrm, uv, ntris, spheres, nspheres, leaf_size, builder, devices[0], &first);
+    if (rc) return rc;
+    vmx_multi *m = new vmx_multi();
+    m->replica.push_back(first);
+    int ndev = 0;
+    (void)hipGetDeviceCount(&ndev);
+    for (uint32_t i = 1; i < ndevices; ++i) {
+        if (devices[i] < 0 || devices[i] >= ndev) {
+            vmx_multi_destroy(m);
+            return fail(VMX_ERR_NO_DEVICE, "device ordinal out of range");
+        }
+        vmx_scene *sc = new vmx_scene();  // replica: shares the host-side build, uploads to its own device
+        sc->device = devices[i];
+        sc->ntris = first->ntris, sc->leaf_size = first->leaf_size;
+        sc->bvh = first->bvh;
+        sc->spheres = first->spheres;
+        rc = scene_upload(sc);
+        if (rc) {
+            const std::string keep = g_err;
+            vmx_scene_destroy(sc);
+            vmx_multi_destroy(m);
+            return fail(rc, keep);
+        }
+        m->replica.push_back(sc);
+        // direct peer copies into the root's gather buffer (xGMI); without peer access the runtime stages
+        // the copy through the host, which is slower but still correct
+        if (devices[i] != devices[0]) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
+                (void)hipSetDevice(devices[i]);
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+    }
+    *out = m;
+    return VMX_OK;
+}
+
+int vmx_multi_destroy(vmx_multi *m) {
+    if (!m) return VMX_OK;
+    if (!m->replica.empty()) (void)hipSetDevice(m->replica[0]->device);
+    m->gathered.release(), m->frame.release();
+    for (vmx_scene *sc : m->replica) vmx_scene_destroy(sc);
+    delete m;
+    return VMX_OK;
+}
+
+uint32_t vmx_multi_world(const vmx_multi *m) { return m ? (uint32_t)m->replica.size() : 0u; }
+
+int vmx_multi_bind_texture(vmx_multi *m, const float *data, uint32_t width, uint32_t height, uint32_t channels) {
+    if (!m) return fail(VMX_ERR_INVALID, "NULL argument");
+    for (vmx_scene *sc : m->replica) {
+        const int rc = vmx_scene_bind_texture(sc, data, width, height, channels);
+        if (rc) return rc;
+    }
+    return VMX_OK;
+}
+
+int vmx_multi_render(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, float *out_rgbaz, vmx_stats *stats) {
+    if (!m || !cam || !opts || !out_rgbaz) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    return multi_render(m, cam, opts, out_rgbaz, nullptr, stats,
+                        [&](vmx_scene *sc, const vmx_opts *o, float *d_out, vmx_stats *st) {
+                            return render_impl(sc, cam, o, d_out, sc->stream, st);
+                        });
+}
+
+int vmx_multi_render_device(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, void *d_out_rgbaz,
+                            vmx_stats *stats) {
+    if (!m || !cam || !opts || !d_out_rgbaz) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    return multi_render(m, cam, opts, nullptr, d_out_rgbaz, stats,
+                        [&](vmx_scene *sc, const vmx_opts *o, float *d_out, vmx_stats *st) {
+                            return render_impl(sc, cam, o, d_out, sc->stream, st);
+                        });
+}
+
+int vmx_multi_render_bruteforce(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
+                                float *out_rgbaz, vmx_stats *stats) {
+    if (!m || !cam || !opts || !out_rgbaz) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    return multi_render(m, cam, opts, out_rgbaz, nullptr, stats,
+                        [&](vmx_scene *sc, const vmx_opts *o, float *d_out, vmx_stats *st) {
+                            return bruteforce_impl(sc, cam, o, flags, d_out, sc->stream, st);
+                        });
 }
 
 } /* extern "C" */

@@ -196,6 +196,67 @@ class Scene:
         return st.as_dict()
 
 
+class MultiScene:
+    """One process, several devices (vmx_multi_*): scene replicas render interleaved stripes, the packed
+    stripes are gathered device-to-device on devices[0] and de-interleaved there."""
+
+    def __init__(self, pos, nrm, uv=None, devices=(0,), spheres=None, leaf_size=4, builder=L.VMX_BVH_REFERENCE):
+        pos = _f32(pos).reshape(-1, 9)
+        nrm = _f32(nrm).reshape(-1, 9)
+        uvp = None
+        if uv is not None:
+            uv = _f32(uv).reshape(-1, 6)
+            uvp = uv.ctypes.data
+        self._spheres = spheres
+        sp, nsp = (None, 0) if spheres is None else (C.addressof(spheres), len(spheres))
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        L.check(L.lib().vmx_multi_create(pos.ctypes.data, nrm.ctypes.data, uvp, pos.shape[0], sp, nsp, int(leaf_size),
+                                         int(builder), devs, len(devices), C.byref(h)))
+        self._h = h
+        self.world = L.lib().vmx_multi_world(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().vmx_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def bind_texture(self, data):
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        c = 1 if data.ndim == 2 else data.shape[2]
+        L.check(L.lib().vmx_multi_bind_texture(self._h, data.ctypes.data, data.shape[1], data.shape[0], c))
+
+    def render(self, cam, opts):
+        out = np.empty((cam.image_res[1], cam.image_res[0], 5), np.float32)
+        st = L.Stats()
+        L.check(L.lib().vmx_multi_render(self._h, C.byref(cam), C.byref(opts), out.ctypes.data, C.byref(st)))
+        return out, st.as_dict()
+
+    def render_device(self, cam, opts, d_out_ptr):
+        st = L.Stats()
+        L.check(L.lib().vmx_multi_render_device(self._h, C.byref(cam), C.byref(opts), C.c_void_p(d_out_ptr), C.byref(st)))
+        return st.as_dict()
+
+    def render_bruteforce(self, cam, opts, flags=0):
+        out = np.empty((cam.image_res[1], cam.image_res[0], 5), np.float32)
+        st = L.Stats()
+        L.check(L.lib().vmx_multi_render_bruteforce(self._h, C.byref(cam), C.byref(opts), int(flags), out.ctypes.data,
+                                                    C.byref(st)))
+        return out, st.as_dict()
+
+
 RAYHIT_DTYPE = np.dtype([
     ("location", np.float32, 3), ("distance", np.float32), ("normal", np.float32, 3), ("tri_id", np.int32),
     ("uv", np.float32, 2), ("tri_t", np.float32), ("flags", np.uint32), ("colour", np.float32, 3),
