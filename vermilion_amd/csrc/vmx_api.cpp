@@ -313,19 +313,22 @@ struct Tuning {
 Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     Tuning tn;
     // coherent camera rays do best when a wave starts 64 of them together; incoherent bounce rays
-    // when finished lanes are replaced early (measured: 64 / 16)
-    tn.refill_min = o->reserved[3] ? o->reserved[3] : 16u;
+    // when finished lanes are replaced early: with the quad-cooperative record fetch an idle lane still
+    // costs its share of every fetch, so lanes are refilled as soon as 8 are idle (measured 4/8: 47.7 ms,
+    // 16: 49.4, 32: 55.5 for the bounce stage of the bench frame)
+    tn.refill_min = o->reserved[3] ? o->reserved[3] : 8u;
     tn.refill_primary = o->reserved[3] ? o->reserved[3] : 64u;
     tn.shade_min = o->reserved[4] ? o->reserved[4] : 16u;
     tn.leaf_min = o->reserved[5] ? o->reserved[5] : 0xFFFFFFFFu;  // k_paths only: triangle-step vote (default: majority)
     // LDS stack levels per lane (+1 scratch level), 512 B per level and wave.  Measured on the Sponza
     // stand-in: camera rays rarely go deep and gain from the 8th wave per SIMD that 8 levels leave
-    // room for (52.6 -> 50.6 ms); incoherent bounce rays go deeper and prefer 13 levels at 6 waves to
-    // spilling levels into HBM (61.8 -> 60 ms); the fused kernels keep 10 (7 waves).
+    // room for (52.6 -> 50.6 ms); the bounce kernel, once its record fetch is quad-cooperative, prefers
+    // waves to LDS levels as well (8: 50.0, 9: 49.8, 10: 50.5, 12: 51.5, 13: 54.6 ms; with the per-lane
+    // fetch it preferred 13 levels at 5-6 waves); the fused kernels keep 10 (7 waves).
     const uint32_t cap = o->reserved[6];
     tn.lds_entries = std::min(sc->dev.stack_entries, cap ? cap : 10u);
     tn.lds_primary = std::min(sc->dev.stack_entries, cap ? cap : 8u);
-    tn.lds_bounce = std::min(sc->dev.stack_entries, cap ? cap : 13u);
+    tn.lds_bounce = std::min(sc->dev.stack_entries, cap ? cap : 9u);
     // bounce generations with fewer live paths than this finish in one fused launch (measured on the
     // Sponza stand-in: 512 K -> 16 M = 155.7 -> 152.9 ms fixed spp, 23.6 -> 20.8 ms with early stop)
     tn.tail_threshold = o->reserved[2] ? o->reserved[2] : (16u << 20);
@@ -352,10 +355,6 @@ LaunchCfg paths_cfg(const vmx_scene *sc, uint32_t entries, uint64_t items, int b
     c.block = kPathsBlock;
     c.lds_bytes = (kPathsBlock / 64) * (entries + 1) * 512;
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    if (const char *e = std::getenv("VMX_EXP_BLOCKS")) {  // EXPERIMENT: cap blocks per CU of the persistent kernels
-        const int cap = std::atoi(e);
-        if (cap > 0 && cap < blocks_per_cu) blocks_per_cu = cap;
-    }
     uint64_t grid = (uint64_t)sc->num_cus * (uint64_t)blocks_per_cu;
     const uint64_t need = (items + kPathsBlock - 1) / kPathsBlock;
     if (need < grid) grid = std::max<uint64_t>(1, need);

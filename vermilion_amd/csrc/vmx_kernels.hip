@@ -1100,6 +1100,60 @@ __global__ void k_bounce(SceneDev sc, float r2scale, QueueDev qin, uint32_t max_
 
 
 // ---------------------------------------------------------------------------
+// quad-cooperative record fetch (k_trace_w<1>, k_paths).  A 64-byte record read by ONE lane as four 16-byte
+// loads costs four tag lookups in the vector L1; read by the four lanes of a quad — lane j takes
+// bytes [16 j, 16 j + 16) — it costs one.  Load i of a step brings the record of quad-lane i, so
+// afterwards lane j holds piece j of the four records of its quad; a 4x4 transpose inside every
+// quad (two butterfly stages, one v_cndmask_b32_dpp per dword and stage: D = vcc ? src1 : dpp(src0))
+// hands every lane the four pieces of its own record.  tools/ta_probe.hip measures both forms.
+// ---------------------------------------------------------------------------
+#define VMX_XCHG_PAIR(NAME, PERM)                                                                                     \
+    __device__ __forceinline__ void NAME(const float4 &p, const float4 &q, float4 &po, float4 &qo,                    \
+                                         unsigned long long keep_p, unsigned long long keep_q) {                     \
+        asm volatile("s_nop 1\n\t"                                                                                   \
+                     "s_mov_b64 vcc, %16\n\t"                                                                        \
+                     "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"          \
+                     "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"          \
+                     "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"         \
+                     "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"         \
+                     "s_mov_b64 vcc, %17\n\t"                                                                        \
+                     "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"          \
+                     "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"          \
+                     "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf\n\t"         \
+                     "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:" PERM " row_mask:0xf bank_mask:0xf"             \
+                     : "=&v"(po.x), "=&v"(po.y), "=&v"(po.z), "=&v"(po.w), "=&v"(qo.x), "=&v"(qo.y), "=&v"(qo.z),    \
+                       "=&v"(qo.w)                                                                                   \
+                     : "v"(p.x), "v"(p.y), "v"(p.z), "v"(p.w), "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w), "s"(keep_p),  \
+                       "s"(keep_q)                                                                                   \
+                     : "vcc");                                                                                       \
+    }
+VMX_XCHG_PAIR(xchg_pair_1, "[1,0,3,2]")
+VMX_XCHG_PAIR(xchg_pair_2, "[2,3,0,1]")
+#undef VMX_XCHG_PAIR
+
+// Fetches, for every lane whose `off` is not ~0, the 64 bytes at base + off (off: 32-bit byte offset of the
+// lane's node or triangle record, 16-byte aligned) into q0..q3.  Must be called with all 64 lanes active.
+__device__ __forceinline__ void quad_fetch_record(const char *base, uint32_t off, uint32_t lane, float4 &q0, float4 &q1,
+                                                  float4 &q2, float4 &q3) {
+    const uint32_t piece = (lane & 3u) << 4;
+    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0, x2 = x0, x3 = x0;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
+    const uint32_t r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0x55, 0xF, 0xF, true);  // [1,1,1,1]
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0xAA, 0xF, 0xF, true);  // [2,2,2,2]
+    const uint32_t r3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0xFF, 0xF, 0xF, true);  // [3,3,3,3]
+    if (r0 != 0xFFFFFFFFu) x0 = *(const float4 *)(base + r0 + piece);
+    if (r1 != 0xFFFFFFFFu) x1 = *(const float4 *)(base + r1 + piece);
+    if (r2 != 0xFFFFFFFFu) x2 = *(const float4 *)(base + r2 + piece);
+    if (r3 != 0xFFFFFFFFu) x3 = *(const float4 *)(base + r3 + piece);
+    float4 a0, a1, a2, a3;
+    xchg_pair_1(x0, x1, a0, a1, 0x5555555555555555ull, 0xAAAAAAAAAAAAAAAAull);  // lanes ^1: even lanes keep (x0, x2)
+    xchg_pair_1(x2, x3, a2, a3, 0x5555555555555555ull, 0xAAAAAAAAAAAAAAAAull);
+    xchg_pair_2(a0, a2, q0, q2, 0x3333333333333333ull, 0xCCCCCCCCCCCCCCCCull);  // lanes ^2: lanes 0,1 of a quad keep (a0, a1)
+    xchg_pair_2(a1, a3, q1, q3, 0x3333333333333333ull, 0xCCCCCCCCCCCCCCCCull);
+}
+
+
+// ---------------------------------------------------------------------------
 // k_paths — persistent waves with per-lane refill.
 //
 // Every lane runs the state machine  fetch -> traverse (one BVH node per loop
@@ -1149,7 +1203,6 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
     uint2 *ovf = (uint2 *)wk.overflow_stack +
                  ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * wk.overflow_entries) * 64 + lane;
     const float4 *__restrict__ inner = (const float4 *)sc.inner;
-    const float4 *__restrict__ tris = (const float4 *)sc.tris;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     constexpr uint32_t kReserve = 256;
 
@@ -1286,9 +1339,14 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
         //         every traversing lane does its triangle step or its inner-node step
         auto step = [&](auto exact_tag) {
             constexpr bool EXACT = decltype(exact_tag)::value;
+            // the node or triangle record of every traversing lane, fetched quad-cooperatively in one phase
+            // (quad_fetch_record; inner and triangle records share one allocation, SceneDev::tri_off)
+            float4 q0, q1, q2, q3;
+            quad_fetch_record((const char *)inner,
+                              cur >= kPop && (int)cur >= 0 ? 0xFFFFFFFFu
+                              : ((int)cur < 0 ? sc.tri_off + (cur & kLeafStartMask) * 48u : (cur << 6)),
+                              lane, q0, q1, q2, q3);
             if (cur < kPop) {
-                const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2];
-                const float2 q3 = ((const float2 *)inner)[cur * 8 + 6];
                 if (COUNT) {
                     if (P.depth == 0) c0.inner++;
                     else c1.inner++;
@@ -1320,9 +1378,8 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                 cur = popn ? kPop : (go_right ? rref : lref);
             } else if ((int)cur < 0) {
                 // one triangle (triangle.cpp:4-54); the leaf ref itself carries the progress
-                const uint32_t ti = (cur & kLeafStartMask) * 3;
-                const float4 a = tris[ti], b = tris[ti + 1];
-                const float e2z = ((const float *)tris)[ti * 4 + 8];
+                const float4 a = q0, b = q1;
+                const float e2z = q2.x;
                 if (COUNT) {
                     if (P.depth == 0) c0.tris++;
                     else c1.tris++;
@@ -1691,6 +1748,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
     }
 }
 
+
 // ---------------------------------------------------------------------------
 // k_trace_w — k_trace_q's production form (no counters), written for the
 // limit the SQ counters show this loop runs at: instruction delivery.  One
@@ -1747,6 +1805,71 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     auto step = [&](auto exact_tag, auto oct_tag) {
         constexpr bool EXACT = decltype(exact_tag)::value;  // NaN-exact box form
         constexpr bool OCT = decltype(oct_tag)::value;      // uniform steps read near-plane-first records
+        if constexpr (SRC == 1) {
+            // ---- bounce rays: ONE fetch phase per step.  Incoherent rays put inner-node lanes and leaf lanes in
+            // the same wave at every step; fetched separately (node loads, wait, box math; triangle loads, wait,
+            // triangle math) a wave-step pays two dependent memory round trips, and this kernel is bound by that
+            // latency (SQ_WAIT_ANY 67 % of its wave cycles, 5 waves per SIMD; profiles/).  Inner records and
+            // triangle records live in one allocation (SceneDev::tri_off), so every traversing lane forms a
+            // 32-bit byte offset to ITS record, all of them load 56 bytes in one set of four loads, and the wave
+            // waits once.  Same tests per ray in the same order (bvh.cpp:47-145).
+            const bool leaf = (int)cur < 0;
+            float4 q0, q1, q2, q3;
+            // byte offset of this lane's record, ~0 while the lane is not traversing
+            quad_fetch_record((const char *)inner,
+                              cur == kIdle ? 0xFFFFFFFFu : (leaf ? sc.tri_off + (cur & kLeafStartMask) * 48u : (cur << 6)),
+                              lane, q0, q1, q2, q3);
+            if (cur != kIdle) {
+                if (!leaf) {
+                    const float a0 = (q0.x - ox) * ix, a1 = (q0.y - oy) * iy, a2 = (q0.z - oz) * iz;
+                    const float a3 = (q0.w - ox) * ix, a4 = (q1.x - oy) * iy, a5 = (q1.y - oz) * iz;
+                    const float b0 = (q1.z - ox) * ix, b1 = (q1.w - oy) * iy, b2 = (q2.x - oz) * iz;
+                    const float b3 = (q2.y - ox) * ix, b4 = (q2.z - oy) * iy, b5 = (q2.w - oz) * iz;
+                    float tn0, tf0, tn1, tf1;
+                    if (EXACT) {
+                        box_net_exact(a0, a1, a2, a3, a4, a5, tn0, tf0);
+                        box_net_exact(b0, b1, b2, b3, b4, b5, tn1, tf1);
+                    } else {
+                        box_net(a0, a1, a2, a3, a4, a5, tn0, tf0);
+                        box_net(b0, b1, b2, b3, b4, b5, tn1, tf1);
+                    }
+                    const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+                    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+                    const bool both = h0 && h1;
+                    const bool go_right = h1 && (!h0 || tn1 < tn0);  // both: the strictly closer right child; one: that child
+                    if (both) {
+                        const uint2 e = make_uint2(go_right ? lref : rref, __float_as_uint(go_right ? tn0 : tn1));
+                        stack_push(stk, ovf, lds_entries, sp, e);
+                        ++sp;
+                    }
+                    const float near = go_right ? tn1 : tn0;
+                    // no child hit, or the child taken directly fails `near > t` (bvh.cpp:69): pop
+                    cur = (!(h0 || h1) || near > best) ? kPop : (go_right ? rref : lref);
+                } else {
+                    // one triangle of the leaf (triangle.cpp:4-54): q0 = (v0, e1.x) q1 = (e1.yz, e2.xy) q2.x = e2.z
+                    const float e1x = q0.w, e1y = q1.x, e1z = q1.y, e2x = q1.z, e2y = q1.w, e2z = q2.x;
+                    float pvx, pvy, pvz;
+                    cross3(dx, dy, dz, e2x, e2y, e2z, pvx, pvy, pvz);
+                    const float det = dot3(e1x, e1y, e1z, pvx, pvy, pvz);
+                    const float inv_det = 1.0f / det;
+                    const float tx = ox - q0.x, ty = oy - q0.y, tz = oz - q0.z;
+                    const float u = dot3(tx, ty, tz, pvx, pvy, pvz) * inv_det;
+                    float qx, qy, qz;
+                    cross3(tx, ty, tz, e1x, e1y, e1z, qx, qy, qz);
+                    const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+                    const float dist = dot3(e2x, e2y, e2z, qx, qy, qz) * inv_det;
+                    const bool parallel = fabsf(det) <= 9.99999993922529e-09f;
+                    const bool u_out = (u < 0.0f) || (u > 1.0f);
+                    const bool v_out = (v < 0.0f) || (u + v > 1.0f);
+                    const bool hit = !parallel && !u_out && !v_out && (dist > 0.0f);
+                    if (hit && dist < best) {  // strict <: first tested wins ties (bvh.cpp:90)
+                        best = dist;
+                        slot = (int)(cur & kLeafStartMask);
+                    }
+                    cur = (((cur >> kLeafCountShift) & 31u) == 1u) ? kPop : cur + (1u - (1u << kLeafCountShift));
+                }
+            }
+        } else
         // inner references are the values below kPop; leaf references have bit 31; kPop/kBottom/kIdle lie between
         if (cur < kPop) {
             // ---- inner node: both children boxes (bbox.cpp:70-83), nearer child first (bvh.cpp:103-132)
