@@ -1131,20 +1131,22 @@ VMX_XCHG_PAIR(xchg_pair_1, "[1,0,3,2]")
 VMX_XCHG_PAIR(xchg_pair_2, "[2,3,0,1]")
 #undef VMX_XCHG_PAIR
 
-// Fetches, for every lane whose `off` is not ~0, the 64 bytes at base + off (off: 32-bit byte offset of the
-// lane's node or triangle record, 16-byte aligned) into q0..q3.  Must be called with all 64 lanes active.
+// Fetches the 64 bytes at base + off (off: 32-bit byte offset of the lane's node or triangle record, 16-byte
+// aligned) into q0..q3 of every lane.  A lane that is not traversing passes off = 0 (the first record: always
+// there, and hot): loading for it unconditionally is cheaper than masking the four loads.  Must be called with
+// all 64 lanes active.
 __device__ __forceinline__ void quad_fetch_record(const char *base, uint32_t off, uint32_t lane, float4 &q0, float4 &q1,
                                                   float4 &q2, float4 &q3) {
     const uint32_t piece = (lane & 3u) << 4;
-    float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0, x2 = x0, x3 = x0;
     const uint32_t r0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0x00, 0xF, 0xF, true);  // quad_perm [0,0,0,0]
     const uint32_t r1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0x55, 0xF, 0xF, true);  // [1,1,1,1]
     const uint32_t r2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0xAA, 0xF, 0xF, true);  // [2,2,2,2]
     const uint32_t r3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)off, 0xFF, 0xF, 0xF, true);  // [3,3,3,3]
-    if (r0 != 0xFFFFFFFFu) x0 = *(const float4 *)(base + r0 + piece);
-    if (r1 != 0xFFFFFFFFu) x1 = *(const float4 *)(base + r1 + piece);
-    if (r2 != 0xFFFFFFFFu) x2 = *(const float4 *)(base + r2 + piece);
-    if (r3 != 0xFFFFFFFFu) x3 = *(const float4 *)(base + r3 + piece);
+    // (one 32-bit offset per load: scalar base + vector offset addressing, no 64-bit address arithmetic)
+    const float4 x0 = *(const float4 *)(base + (uint32_t)(r0 + piece));
+    const float4 x1 = *(const float4 *)(base + (uint32_t)(r1 + piece));
+    const float4 x2 = *(const float4 *)(base + (uint32_t)(r2 + piece));
+    const float4 x3 = *(const float4 *)(base + (uint32_t)(r3 + piece));
     float4 a0, a1, a2, a3;
     xchg_pair_1(x0, x1, a0, a1, 0x5555555555555555ull, 0xAAAAAAAAAAAAAAAAull);  // lanes ^1: even lanes keep (x0, x2)
     xchg_pair_1(x2, x3, a2, a3, 0x5555555555555555ull, 0xAAAAAAAAAAAAAAAAull);
@@ -1343,7 +1345,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
             // (quad_fetch_record; inner and triangle records share one allocation, SceneDev::tri_off)
             float4 q0, q1, q2, q3;
             quad_fetch_record((const char *)inner,
-                              cur >= kPop && (int)cur >= 0 ? 0xFFFFFFFFu
+                              cur >= kPop && (int)cur >= 0 ? 0u
                               : ((int)cur < 0 ? sc.tri_off + (cur & kLeafStartMask) * 48u : (cur << 6)),
                               lane, q0, q1, q2, q3);
             if (cur < kPop) {
@@ -1815,9 +1817,9 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             // waits once.  Same tests per ray in the same order (bvh.cpp:47-145).
             const bool leaf = (int)cur < 0;
             float4 q0, q1, q2, q3;
-            // byte offset of this lane's record, ~0 while the lane is not traversing
+            // byte offset of this lane's record (0 while the lane is not traversing)
             quad_fetch_record((const char *)inner,
-                              cur == kIdle ? 0xFFFFFFFFu : (leaf ? sc.tri_off + (cur & kLeafStartMask) * 48u : (cur << 6)),
+                              cur == kIdle ? 0u : (leaf ? sc.tri_off + (cur & kLeafStartMask) * 48u : (cur << 6)),
                               lane, q0, q1, q2, q3);
             if (cur != kIdle) {
                 if (!leaf) {
