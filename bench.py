@@ -32,6 +32,16 @@ from vermilion_amd import dist as vdist  # noqa: E402
 from vermilion_amd import scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue roof: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz max clock
+# (MI355X_MICROARCH.md "Wave scheduling", "Per-instruction cycle constants") -> wave-level instructions per second
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
+KERNEL_TEXT = {
+    "trace_camera": "k_trace_w<0> (persistent BVH traversal of the camera rays)",
+    "trace_bounce": "k_trace_w<1> (persistent BVH traversal of a bounce generation, quad-cooperative record fetch)",
+    "shade_camera": "k_shade<0> (RayCast tail + Radiance step of the camera rays)",
+    "shade_bounce": "k_shade<1>", "tail": "k_paths<2> (fused tail of the last bounce generations)",
+    "raygen": "k_raygen", "resolve": "k_resolve", "fused": "k_paths<0>",
+}
 
 
 def alg_bytes(stage):
@@ -57,6 +67,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=32, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline frame (no early-stop frame, no SAH-tree frame): the profiling runs of tools/pmc.sh")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (frames travel through host memory)")
     ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (rehearsal)")
@@ -97,6 +109,7 @@ def main():
         opts = va.make_opts(seed=args.seed, early_stop=early_stop, sampling=va.VMX_SAMPLING_PARITY, rank=rank,
                             world=world, stripe_rows=stripe, collect_counters=counters)
         st = sc.render_device(cam, opts, local.data_ptr(), stream)
+        st["kernels"] = sc.timings()  # per-kernel hipEvent durations of this frame (on the render stream)
         src = local if args.backend == "nccl" or world == 1 else local.cpu()
         frame = vdist.gather_frame(src, W, H, stripe, rank, world, dst=0)
         return st, frame
@@ -131,13 +144,15 @@ def main():
     value = rays / dt / 1e6
 
     # reference-faithful frame (early stop on, pathtracer.cpp:290-311), same frame otherwise
-    step(early_stop=True)
-    es_k = max(1, min(args.steps, 3))
-    es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
+    es_k = 0
+    if not args.no_extras:
+        step(early_stop=True)
+        es_k = max(1, min(args.steps, 3))
+        es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
 
     # §8 f-1 quality builder (binned SAH, not the reference's topology): same frame, extra figure only
     q_info = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         qsc = va.Scene(pos, nrm, uv, device=dev_index, builder=va._lib.VMX_BVH_SAH)
         qopts = va.make_opts(seed=args.seed, early_stop=False, collect_counters=True)
         qc = qsc.render_device(cam, qopts, local.data_ptr(), stream)
@@ -162,18 +177,67 @@ def main():
 
     if rank == 0:
         prim_ms = sum(s["primary"]["ms"] for s in stats)
-        prim_launches = sum(s["primary"]["launches"] for s in stats)
-        bytes_per_launch = trace_alg_bytes(cst["primary"]) / max(cst["primary"]["launches"], 1)
-        avg_ms = prim_ms / max(prim_launches, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1 and (W, H, spp, args.scene) == (1920, 1080, 256, "sponza260k"):
+        # per-kernel device time of the timed steps, measured live (hipEvent pairs on the render stream)
+        kms = {k: sum(s["kernels"][k]["ms"] for s in stats) / args.steps for k in stats[0]["kernels"]}
+        klaunch = {k: sum(s["kernels"][k]["launches"] for s in stats) for k in stats[0]["kernels"]}
+        dominant = max(kms, key=kms.get)
+        prof = None
+        ppath = os.path.join(ROOT, "profiles", "counters.json")
+        if os.path.exists(ppath) and world == 1 and (W, H, spp, args.scene) == (1920, 1080, 256, "sponza260k"):
             try:
-                traffic = json.load(open(tpath)).get("trace_kernel_hbm_bytes_per_launch")
+                prof = json.load(open(ppath))["kernels"]
             except Exception:
-                traffic = None
-        total_rays_frame = cst["rays_primary"] + cst["rays_secondary"]
+                prof = None
+
+        def kernel_roof(name):
+            """VALU-issue roofline of one kernel: wave-level VALU instructions per launch (rocprofv3 PMC of this
+            exact frame, profiles/counters.json) / the launch duration measured here"""
+            n = max(klaunch[name], 1)
+            avg_ms = kms[name] * args.steps / n
+            r = {"kernel": KERNEL_TEXT.get(name, name), "avg_launch_ms": round(avg_ms, 4),
+                 "launches_per_step": n // max(args.steps, 1), "ms_per_step": round(kms[name], 3)}
+            d = (prof or {}).get(name, {}).get("derived")
+            if d and avg_ms > 0:
+                # (a kernel launched more than once per step: counters are those of its longest launch; the bench
+                # frame launches each traversal kernel once)
+                ach = d["valu_wave_insts_per_launch"] / (avg_ms * 1e-3)
+                r.update({"bound": "valu_issue", "achieved": round(ach / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
+                          "unit": "Gwave-inst/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
+                          "traffic": d.get("hbm_bytes_per_launch"),
+                          "valu_wave_insts_per_launch": int(d["valu_wave_insts_per_launch"]),
+                          "valu_lane_utilization": round(d.get("valu_lane_utilization", 0.0), 3),
+                          "effective_clock_GHz_under_pmc": round(d.get("effective_clock_GHz", 0.0), 3),
+                          "l1_accesses_per_clk_per_cu": round(d["l1_accesses_per_launch"] / (avg_ms * 1e-3) / 2.4e9 / 256, 3)
+                          if "l1_accesses_per_launch" in d else None,
+                          "hbm_frac_measured": round(d["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                          if "hbm_bytes_per_launch" in d else None})
+            return r
+
+        roof = kernel_roof(dominant)
+        if "bound" not in roof:  # no PMC profile for this configuration: say so instead of inventing a fraction
+            roof.update({"bound": "valu_issue", "achieved": None, "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
+                         "unit": "Gwave-inst/s", "frac": None, "traffic": None,
+                         "note": "profiles/counters.json holds no counters for this workload"})
+        roof["source"] = "profiles/counters.json (rocprofv3 --pmc, tools/pmc.sh + tools/make_counters.py) x live hipEvent durations"
+        roof["other_kernels"] = {k: kernel_roof(k) for k in ("trace_camera", "trace_bounce", "shade_camera", "tail")
+                                 if k != dominant and kms.get(k, 0) > 0}
+        # SURVEY §8(d)'s algorithmic bytes, kept as the secondary view: the scene (34 MB) is cache-resident, so
+        # HBM is not the roof of this path (measured HBM traffic is `hbm_frac_measured` of peak)
+        cam_bytes = trace_alg_bytes(cst["primary"]) / max(cst["primary"]["launches"], 1)
+        cam_ms = kms["trace_camera"] * args.steps / max(klaunch["trace_camera"], 1) if klaunch.get("trace_camera") else 0
+        roof["algorithmic"] = {
+            "what": "SURVEY 8(d) bytes per ray x rays of the camera-ray launch / its duration, against the 8 TB/s HBM "
+                    "peak: > 1 because the records come from L2 / scalar cache / Infinity Cache, not from HBM",
+            "alg_bytes_per_launch": int(cam_bytes),
+            "alg_GBs": round(cam_bytes / (cam_ms * 1e-3) / 1e9, 1) if cam_ms else None,
+            "alg_frac_of_hbm_peak": round(cam_bytes / (cam_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if cam_ms else None,
+            "alg_bytes_per_ray": round(trace_alg_bytes(cst["primary"]) / max(cst["primary"]["rays"], 1), 1),
+            "alg_bytes_per_ray_whole_path": round(alg_bytes(cst["primary"]) / max(cst["primary"]["rays"], 1), 1),
+            "inner_visits_per_ray": round(cst["primary"]["inner_visits"] / max(cst["primary"]["rays"], 1), 2),
+            "tri_tests_per_ray": round(cst["primary"]["tri_tests"] / max(cst["primary"]["rays"], 1), 2),
+            "bounce_inner_visits_per_ray": round(cst["bounce"]["inner_visits"] / max(cst["bounce"]["rays"], 1), 2),
+            "bounce_tri_tests_per_ray": round(cst["bounce"]["tri_tests"] / max(cst["bounce"]["rays"], 1), 2),
+        }
         out = {
             "metric": "Mrays/sec (primary+secondary), 1920x1080 Sponza",
             "value": round(value, 2),
@@ -194,22 +258,8 @@ def main():
                 "parallelism": f"stripes{stripe}x{world}" if world > 1 else "single",
                 "bvh": {"nodes": desc["n_nodes"], "max_depth": desc["max_depth"], "leaf_size": desc["leaf_size"]},
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_trace_w<0> (persistent BVH traversal of the depth-0 rays)",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "alg_bytes_per_launch": int(bytes_per_launch),
-                "avg_launch_ms": round(avg_ms, 4),
-                "launches_per_step": prim_launches // max(args.steps, 1),
-                "alg_bytes_per_ray": round(trace_alg_bytes(cst["primary"]) / max(cst["primary"]["rays"], 1), 1),
-                "alg_bytes_per_ray_whole_path": round(alg_bytes(cst["primary"]) / max(cst["primary"]["rays"], 1), 1),
-                "inner_visits_per_ray": round(cst["primary"]["inner_visits"] / max(cst["primary"]["rays"], 1), 2),
-                "tri_tests_per_ray": round(cst["primary"]["tri_tests"] / max(cst["primary"]["rays"], 1), 2),
-            },
+            "roofline": roof,
+            "kernel_ms_per_step": {k: round(v, 3) for k, v in kms.items() if v > 0},
             "stage_ms_per_step": {
                 "primary_trace": round(prim_ms / args.steps, 3),
                 "bounce_trace_and_tail": round(sum(s["bounce"]["ms"] for s in stats) / args.steps, 3),
@@ -218,14 +268,15 @@ def main():
             },
             "whole_frame_alg_GBs": round((alg_bytes(cst["primary"]) + alg_bytes(cst["bounce"])) / (ms_per_step * 1e-3) / 1e9, 1)
             if world == 1 else None,
-            "reference_frame": {
+        }
+        if es_k:
+            out["reference_frame"] = {
                 "what": "same frame with the reference's early-stop rule on (pathtracer.cpp:290-311)",
                 "ms_per_frame": round(es_dt / es_k * 1e3, 3),
                 "Mrays_per_s": round(es_rays / es_dt / 1e6, 2),
                 "rays_per_frame": int(es_rays / es_k),
                 "passes": es_stats[0]["passes"],
-            },
-        }
+            }
         if q_info:
             out["quality_bvh"] = q_info
         if world == 1 and not args.no_cpu_baseline:

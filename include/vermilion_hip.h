@@ -122,6 +122,25 @@ typedef struct vmx_stats {
     vmx_stage_stats shade;   /* ms/launches only: the shading kernels of the split wavefront */
 } vmx_stats;
 
+/* per-kernel device time (hipEvent pairs on the render stream) of the LAST render / radiance call on
+ * a scene: what bench.py's roofline object is computed from (the dominant kernel of a step) */
+#define VMX_K_RAYGEN 0        /* k_raygen                                                  */
+#define VMX_K_TRACE_CAMERA 1  /* k_trace_w<0>: BVH traversal of the camera rays            */
+#define VMX_K_SHADE_CAMERA 2  /* k_shade<0>                                                */
+#define VMX_K_TRACE_BOUNCE 3  /* k_trace_w<1>: BVH traversal of the bounce generations     */
+#define VMX_K_SHADE_BOUNCE 4  /* k_shade<1>                                                */
+#define VMX_K_TAIL 5          /* k_paths<2>: fused kernel that finishes the last generations */
+#define VMX_K_FUSED 6         /* k_paths<0>: whole small passes in one fused kernel        */
+#define VMX_K_RESOLVE 7       /* k_resolve                                                 */
+#define VMX_K_BRUTEFORCE 8    /* k_bruteforce                                              */
+#define VMX_K_OTHER 9         /* first-generation kernels (pipeline forms 2, 3)            */
+#define VMX_K_COUNT 10
+typedef struct vmx_timings {
+    double ms[VMX_K_COUNT];          /* summed over the launches of the call */
+    double longest_ms[VMX_K_COUNT];  /* the longest single launch            */
+    uint64_t launches[VMX_K_COUNT];
+} vmx_timings;
+
 typedef struct vmx_scene_desc {
     uint32_t ntris;
     uint32_t nspheres;
@@ -198,6 +217,7 @@ int vmx_scene_destroy(vmx_scene *scene);
 int vmx_scene_bind_texture(vmx_scene *scene, const float *data, uint32_t width, uint32_t height,
                            uint32_t channels);
 int vmx_scene_describe(const vmx_scene *scene, vmx_scene_desc *out);
+int vmx_scene_timings(const vmx_scene *scene, vmx_timings *out);
 /*
  * Host-side BVH topology in the reference's flat layout (bvh.h:11-14): per
  * node start, nPrims, rightOffset ([n_nodes] each, any may be NULL), bbox

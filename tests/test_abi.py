@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_struct_layouts_match_header(tmp_path):
     names = {"vmx_sphere": L.Sphere, "vmx_camera": L.CameraDesc, "vmx_opts": L.Opts, "vmx_stage_stats": L.StageStats,
-             "vmx_stats": L.Stats, "vmx_scene_desc": L.SceneDesc, "vmx_rayhit": L.RayHit}
+             "vmx_stats": L.Stats, "vmx_scene_desc": L.SceneDesc, "vmx_rayhit": L.RayHit, "vmx_timings": L.Timings}
     prog = '#include <stdio.h>\n#include <stddef.h>\n#include "vermilion_hip.h"\nint main(void){\n'
     for n in names:
         prog += f'printf("{n} %zu\\n", sizeof({n}));\n'
@@ -54,6 +54,8 @@ def test_struct_layouts_match_header(tmp_path):
     assert int(out["off_primary"]) == L.Stats.primary.offset
     assert int(out["off_flags"]) == L.RayHit.flags.offset
     assert C.sizeof(L.RayHit) == 64 and C.sizeof(L.Sphere) == 48
+    src = open(HEADER).read()
+    assert len(L.K_NAMES) == int(re.search(r"#define VMX_K_COUNT (\d+)", src).group(1))
 
 
 def test_default_spheres_are_the_reference_eight(hip_lib):

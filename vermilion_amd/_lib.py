@@ -116,6 +116,18 @@ class SceneDesc(C.Structure):
     ]
 
 
+K_NAMES = ["raygen", "trace_camera", "shade_camera", "trace_bounce", "shade_bounce", "tail", "fused", "resolve",
+           "bruteforce", "other"]  # VMX_K_* of vermilion_hip.h
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms", C.c_double * 10), ("longest_ms", C.c_double * 10), ("launches", C.c_uint64 * 10)]
+
+    def as_dict(self):
+        return {n: {"ms": self.ms[i], "longest_ms": self.longest_ms[i], "launches": self.launches[i]}
+                for i, n in enumerate(K_NAMES)}
+
+
 class RayHit(C.Structure):
     _fields_ = [
         ("location", C.c_float * 3),
@@ -143,6 +155,7 @@ SYMBOLS = {
     "vmx_scene_destroy": (C.c_int, [_P]),
     "vmx_scene_bind_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vmx_scene_describe": (C.c_int, [_P, C.POINTER(SceneDesc)]),
+    "vmx_scene_timings": (C.c_int, [_P, C.POINTER(Timings)]),
     "vmx_scene_bvh": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "vmx_trace": (C.c_int, [_P, _P, _P, C.c_uint32, _P, _P]),
     "vmx_raycast": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),

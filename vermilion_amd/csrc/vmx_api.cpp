@@ -149,6 +149,7 @@ struct vmx_scene {
     std::mutex mu;
     Workspace ws;
     uint32_t block = 256;
+    vmx_timings timings{};  // per-kernel durations of the last render on this scene
 };
 
 namespace {
@@ -258,7 +259,8 @@ void stage_out(vmx_stage_stats &dst, const StageCounters &c) {
 
 struct TimedLaunch {
     hipEvent_t a, b;
-    int stage;
+    int stage;   // vmx_stats bucket: 0 primary, 1 bounce, 2 shade
+    int kernel;  // VMX_K_* of vmx_timings (per-kernel durations of the last call)
 };
 
 // reads the 16 sub-queue tails; returns total and the largest
@@ -291,7 +293,7 @@ int run_queue(vmx_scene *sc, float r2scale, QueueDev q[2], int cur, void *rad, D
         const bool tail = total <= tail_threshold;
         LaunchCfg cfg = trace_cfg(sc, max_chunks * kSubQueues, bounce_blocks);
         if (!tail) LAUNCH_TRY(launch_zero_u32(q[cur ^ 1].counts, kSubQueues * 32, s));
-        TimedLaunch tl{ws.events.get(), ws.events.get(), 1};
+        TimedLaunch tl{ws.events.get(), ws.events.get(), 1, VMX_K_OTHER};
         if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(tl.a, s));
         LAUNCH_TRY(launch_bounce(sc->dev, r2scale, q[cur], max_chunks, q[cur ^ 1], rad, ctr, count, tail, false,
@@ -412,7 +414,7 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
         rc = bind_stack(sc, tn, entries, cfg.grid, wk);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
-        TimedLaunch tl{ws.events.get(), ws.events.get(), 1};
+        TimedLaunch tl{ws.events.get(), ws.events.get(), 1, tail ? VMX_K_TAIL : VMX_K_TRACE_BOUNCE};
         if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(tl.a, s));
         if (tail) {
@@ -426,7 +428,7 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
         HIP_TRY(hipEventRecord(tl.b, s));
         timed.push_back(tl);
         HIP_TRY(hipMemsetAsync(q[cur ^ 1].counts, 0, kSubQueues * 32 * 4, s));
-        TimedLaunch ts{ws.events.get(), ws.events.get(), 2};
+        TimedLaunch ts{ws.events.get(), ws.events.get(), 2, VMX_K_SHADE_BOUNCE};
         if (!ts.a || !ts.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(ts.a, s));
         LAUNCH_TRY(launch_shade(sc->dev, fr, wk, nopx, pa, q[cur ^ 1], (largest + 255) / 256, ctr, true, s));
@@ -465,7 +467,8 @@ int finish_stats(vmx_scene *sc, hipStream_t s, std::vector<TimedLaunch> &timed, 
     DevCounters h;
     HIP_TRY(hipMemcpy(&h, ws.counters.p, sizeof(h), hipMemcpyDeviceToHost));
     if (h.overflow) return fail(VMX_ERR_NOMEM, "path queue overflow (sub-queues full); lower max paths per pass");
-    if (!stats) return VMX_OK;
+    vmx_stats local_stats;
+    if (!stats) stats = &local_stats;
     std::memset(stats, 0, sizeof(*stats));
     stage_out(stats->primary, h.stage[0]);
     stage_out(stats->bounce, h.stage[1]);
@@ -475,12 +478,18 @@ int finish_stats(vmx_scene *sc, hipStream_t s, std::vector<TimedLaunch> &timed, 
     stats->samples_discarded = h.discarded;
     stats->passes = passes;
     stats->kernel_launches = launches;
+    std::memset(&sc->timings, 0, sizeof(sc->timings));
     for (auto &tl : timed) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, tl.a, tl.b));
-        vmx_stage_stats &st = tl.stage == 0 ? stats->primary : (tl.stage == 1 ? stats->bounce : stats->shade);
-        st.ms += ms;
-        st.launches++;
+        if (tl.stage >= 0) {
+            vmx_stage_stats &st = tl.stage == 0 ? stats->primary : (tl.stage == 1 ? stats->bounce : stats->shade);
+            st.ms += ms;
+            st.launches++;
+        }
+        sc->timings.ms[tl.kernel] += ms;
+        sc->timings.launches[tl.kernel]++;
+        if (ms > sc->timings.longest_ms[tl.kernel]) sc->timings.longest_ms[tl.kernel] = ms;
     }
     float ms = 0.f;
     if (ev0 && ev1) HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
@@ -650,9 +659,10 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         const bool refill = pipeline == 1 || (pipeline == 0 && !split);
         const bool mega = refill || pipeline == 3;
         if (!mega && !split) HIP_TRY(hipMemsetAsync(q[0].counts, 0, kSubQueues * 32 * 4, s));
-        TimedLaunch tl{ws.events.get(), ws.events.get(), 0};
+        TimedLaunch tl{ws.events.get(), ws.events.get(), 0, VMX_K_OTHER};
         if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         if (split) {
+            tl.kernel = VMX_K_TRACE_CAMERA;
             WorkDev wk;
             std::memset(&wk, 0, sizeof(wk));
             wk.heads = ws.heads.p;
@@ -669,12 +679,17 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             rc = bind_stack(sc, tn, tn.lds_primary, cfg.grid, wk);
             if (rc) return rc;
             HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
+            TimedLaunch tg{ws.events.get(), ws.events.get(), -1, VMX_K_RAYGEN};
+            if (!tg.a || !tg.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(tg.a, s));
             LAUNCH_TRY(launch_raygen(fr, wk, px, pa, s));
+            HIP_TRY(hipEventRecord(tg.b, s));
+            timed.push_back(tg);
             HIP_TRY(hipEventRecord(tl.a, s));
             LAUNCH_TRY(launch_trace_q(sc->dev, fr, wk, px, pa, ws.counters.p, count, false, cfg, s));
             HIP_TRY(hipEventRecord(tl.b, s));
             HIP_TRY(hipMemsetAsync(qi[0].counts, 0, kSubQueues * 32 * 4, s));
-            TimedLaunch ts{ws.events.get(), ws.events.get(), 2};
+            TimedLaunch ts{ws.events.get(), ws.events.get(), 2, VMX_K_SHADE_CAMERA};
             if (!ts.a || !ts.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(ts.a, s));
             LAUNCH_TRY(launch_shade(sc->dev, fr, wk, px, pa, qi[0], 0, ws.counters.p, false, s));
@@ -682,6 +697,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             timed.push_back(ts);
             launches += 2;
         } else if (refill) {
+            tl.kernel = VMX_K_FUSED;
             WorkDev wk;
             std::memset(&wk, 0, sizeof(wk));
             wk.heads = ws.heads.p;
@@ -717,8 +733,13 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             if (rc) return rc;
         }
         HIP_TRY(hipMemsetAsync(ws.next_count.p, 0, 8, s));
+        TimedLaunch tr{ws.events.get(), ws.events.get(), -1, VMX_K_RESOLVE};
+        if (!tr.a || !tr.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(tr.a, s));
         LAUNCH_TRY(launch_resolve(fr, ws.active[cur_list].p, n_active, S, split || refill, ws.rad.p, px, ws.active[cur_list ^ 1].p,
                                   ws.next_count.p, d_out, ws.counters.p, s));
+        HIP_TRY(hipEventRecord(tr.b, s));
+        timed.push_back(tr);
         launches++;
         passes++;
         unsigned int h_next[2] = {0, 0};  // [0] pixels still active, [1] pixels that stopped a stratum early
@@ -899,6 +920,12 @@ int vmx_scene_describe(const vmx_scene *sc, vmx_scene_desc *out) {
     out->device_bytes = sc->bvh.inner.size() * sizeof(InnerRecord) + sc->bvh.tris.size() * sizeof(TriRecord) +
                         sc->bvh.attrs.size() * sizeof(AttrRecord) + sc->spheres.size() * sizeof(SphereDev);
     out->device = sc->device;
+    return VMX_OK;
+}
+
+int vmx_scene_timings(const vmx_scene *sc, vmx_timings *out) {
+    if (!sc || !out) return fail(VMX_ERR_INVALID, "NULL argument");
+    *out = sc->timings;
     return VMX_OK;
 }
 
@@ -1169,7 +1196,7 @@ int bruteforce_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, 
     HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
     HIP_TRY(hipEventRecord(ev0, s));
     LaunchCfg cfg = trace_cfg(sc, (npix + sc->block - 1) / sc->block, 4);
-    TimedLaunch tl{ws.events.get(), ws.events.get(), 0};
+    TimedLaunch tl{ws.events.get(), ws.events.get(), 0, VMX_K_BRUTEFORCE};
     if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(tl.a, s));
     LAUNCH_TRY(launch_bruteforce(sc->dev, fr, ws.active[0].p, npix, flags, d_out, ws.counters.p, cfg, s));

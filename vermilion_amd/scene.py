@@ -125,6 +125,12 @@ class Scene:
         L.check(L.lib().vmx_scene_describe(self._h, C.byref(d)))
         return {k: getattr(d, k) for k, _ in d._fields_ if k != "pad"}
 
+    def timings(self):
+        """per-kernel device time of the last render on this scene (vmx_timings)"""
+        t = L.Timings()
+        L.check(L.lib().vmx_scene_timings(self._h, C.byref(t)))
+        return t.as_dict()
+
     def bvh(self):
         n = self.describe()["n_nodes"]
         start = np.zeros(n, np.uint32)
