@@ -61,6 +61,18 @@ def test_multi_render_device_buffer_and_texture():
         assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
 
 
+def test_multi_with_the_device_built_tree():
+    """VMX_BVH_LBVH scenes are built on each device of the list (nothing to share on the host): same frame"""
+    pos, nrm, uv = scenes.lattice()
+    c = scenes.lattice_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 96, 64, 16, back_size=(3.6, 2.4))
+    with va.Scene(pos, nrm, uv, builder=va._lib.VMX_BVH_LBVH) as one, \
+            va.MultiScene(pos, nrm, uv, devices=[0, 0], builder=va._lib.VMX_BVH_LBVH) as multi:
+        ref, _ = one.render(cam, va.make_opts(seed=4))
+        img, _ = multi.render(cam, va.make_opts(seed=4))
+        assert np.array_equal(bits(img), bits(ref))
+
+
 def test_multi_argument_checks():
     pos, nrm, uv = scenes.cornell8()
     with pytest.raises(va.VmxError) as e:

@@ -32,10 +32,28 @@ bool build_bvh(const float *pos, const float *nrm, const float *uv, uint32_t ntr
 bool build_bvh_sah(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                    uint32_t leaf_size, HostBvh &out, std::string &err);
 
-// linear BVH built on the GPU (Morton sort + Karras hierarchy + bottom-up fit, lbvh_build.hip), linearised on
-// the host into the same flat layout; not the reference's topology either
-bool build_bvh_lbvh(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
-                    int device, HostBvh &out, std::string &err);
+// linear BVH built ENTIRELY on the GPU (lbvh_build.hip): Morton sort + Karras hierarchy + bottom-up fit +
+// device-record emission.  The product buffers (`geom` = inner records then triangle records, `attrs`) are
+// device memory handed to the scene; the hierarchy arrays stay in `arena` for lbvh_export_flat.
+struct LbvhDevice {
+    void *arena = nullptr;  // inputs, temporaries, hierarchy
+    size_t arena_bytes = 0;
+    void *geom = nullptr;   // InnerRecord[n_inner] then TriRecord[ntris] (+ 64 bytes of padding)
+    size_t geom_bytes = 0;
+    void *attrs = nullptr;  // AttrRecord[ntris]
+    uint32_t ntris = 0, leaf_size = 4;
+    uint32_t n_inner = 0;   // inner record slots = max(ntris - 1, 1): record i is Karras node i
+    uint32_t tri_off = 0, root_ref = 0, height = 0;
+    // hierarchy (device pointers into the arena): children (bit 31 = sorted primitive), key ranges, boxes,
+    // sorted position -> triangle id
+    uint32_t *left = nullptr, *right = nullptr, *first = nullptr, *last = nullptr, *ids = nullptr;
+    float *leaf_box = nullptr, *node_box = nullptr;
+};
+bool build_bvh_lbvh_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
+                           int device, LbvhDevice &out, std::string &err);
+// reference flat layout (start / nprims / right_offset / bbox / prim_order, n_leaves, max_depth) of such a tree
+bool lbvh_export_flat(const LbvhDevice &d, int device, HostBvh &out, std::string &err);
+void lbvh_release(LbvhDevice &d);
 
 // shared by the builders: input validation; flat tree (start/nprims/right_offset/bbox/prim_order) -> device records
 bool check_bvh_input(const float *pos, const float *nrm, uint32_t ntris, uint32_t &leaf_size, std::string &err);

@@ -1,5 +1,6 @@
 // lbvh_build.hip — BVH construction on the GPU: a linear BVH.
 //
+//   k_lbvh_bounds     centroid bounds (wave min/max + integer atomics on order-preserving float keys)
 //   k_lbvh_keys       63-bit Morton code of each triangle's centroid (21 bits per axis, over the
 //                     centroid bounds) — unique after the triangle index breaks ties in the sort
 //   hipcub radix sort (key, triangle id) pairs
@@ -10,18 +11,23 @@
 //                     node merges its children's boxes (exact: min/max are order-independent) and
 //                     subtree height
 //
-// The host then walks the tree once, depth first, into the reference's flat layout (bvh.h:11-14:
-// pre-order, left child = i + 1, leaf <=> rightOffset == 0), turning every subtree of at most
-// `leaf_size` triangles into one leaf, and hands it to the same flattening as the other builders
-// (bvh_build.cpp).  Like the SAH builder this is NOT the reference's topology: for throughput runs
-// and scenes that change per frame, not for triangle-ID parity runs.  Its parity bar is the same:
-// the reference's traversal run over the exported tree gives bit-identical hits (tests).
+//   k_lbvh_emit_*     the device records the traversal kernels read (InnerRecord / TriRecord /
+//                     AttrRecord), written straight from the hierarchy: every subtree of at most
+//                     `leaf_size` triangles becomes one leaf reference; inner record i is Karras node i
+//
+// Nothing returns to the host during a build (only the root's height, for the stack depth), so scene
+// creation with this builder is a per-frame operation.  The reference's flat layout (bvh.h:11-14) is
+// produced on demand (lbvh_export_flat: vmx_scene_bvh / vmx_scene_describe) by one depth-first host
+// walk over the downloaded hierarchy.  Like the SAH builder this is NOT the reference's topology: for
+// throughput runs and scenes that change per frame, not for triangle-ID parity runs.  Its parity bar is
+// the same: the reference's traversal run over the exported tree gives bit-identical hits (tests).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "bvh_build.h"
 
 namespace vmx {
@@ -54,20 +60,6 @@ __device__ __forceinline__ unsigned long long spread21(uint32_t v) {
     x = (x | x << 4) & 0x10c30c30c30c30c3ull;
     x = (x | x << 2) & 0x1249249249249249ull;
     return x;
-}
-
-__global__ void k_lbvh_keys(const float *__restrict__ pos, uint32_t n, float lox, float loy, float loz, float sx,
-                            float sy, float sz, unsigned long long *__restrict__ keys, uint32_t *__restrict__ ids) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *p = pos + (size_t)i * 9;
-    const float cx = ((p[0] + p[3]) + p[6]) * (1.f / 3.f), cy = ((p[1] + p[4]) + p[7]) * (1.f / 3.f),
-                cz = ((p[2] + p[5]) + p[8]) * (1.f / 3.f);
-    const uint32_t qx = (uint32_t)fminf(fmaxf((cx - lox) * sx, 0.f), 2097151.f);
-    const uint32_t qy = (uint32_t)fminf(fmaxf((cy - loy) * sy, 0.f), 2097151.f);
-    const uint32_t qz = (uint32_t)fminf(fmaxf((cz - loz) * sz, 0.f), 2097151.f);
-    keys[i] = spread21(qx) << 2 | spread21(qy) << 1 | spread21(qz);
-    ids[i] = i;
 }
 
 // common-prefix length of sorted entries i and j (-1 outside the array); equal codes are told
@@ -149,82 +141,244 @@ __global__ void k_lbvh_fit(const float *__restrict__ pos, const uint32_t *__rest
     }
 }
 
-}  // namespace
 
-bool build_bvh_lbvh(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
-                    int device, HostBvh &out, std::string &err) {
-    if (!check_bvh_input(pos, nrm, ntris, leaf_size, err)) return false;
-    const int n = (int)ntris;
-    LB_TRY(hipSetDevice(device));
-    // centroid bounds on the host (one pass over data the host already holds)
+// ---- device records straight from the hierarchy (no host flatten) ------------------------------------
+// Inner record i IS Karras node i (records of nodes inside a collapsed subtree stay unused: the array is
+// ntris - 1 slots, references are indices, so no compaction or renumbering pass is needed); a subtree of at
+// most `leaf_size` triangles becomes a leaf reference (first sorted position, count) in its parent.
+__device__ __forceinline__ uint32_t lbvh_child_ref(uint32_t c, uint32_t leaf_size, const uint32_t *first,
+                                                   const uint32_t *last, const float *leaf_box, const float *node_box,
+                                                   const float *&box) {
+    if (c & 0x80000000u) {
+        const uint32_t p = c & 0x7FFFFFFFu;
+        box = leaf_box + (size_t)p * 6;
+        return kLeafBit | (1u << kLeafCountShift) | p;
+    }
+    box = node_box + (size_t)c * 6;
+    const uint32_t cnt = last[c] - first[c] + 1u;
+    return cnt <= leaf_size ? (kLeafBit | (cnt << kLeafCountShift) | first[c]) : c;
+}
+
+__global__ void k_lbvh_emit_inner(int n, uint32_t leaf_size, const uint32_t *__restrict__ left,
+                                  const uint32_t *__restrict__ right, const uint32_t *__restrict__ first,
+                                  const uint32_t *__restrict__ last, const float *__restrict__ leaf_box,
+                                  const float *__restrict__ node_box, InnerRecord *__restrict__ inner) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    InnerRecord r;
+    if (last[i] - first[i] + 1u <= leaf_size) {  // inside (or the top of) a collapsed subtree: never referenced
+        for (int a = 0; a < 3; ++a) r.lmin[a] = r.lmax[a] = r.rmin[a] = r.rmax[a] = 0.f;
+        r.left = r.right = r.pad0 = r.pad1 = 0;
+        inner[i] = r;
+        return;
+    }
+    const float *lb, *rb;
+    r.left = lbvh_child_ref(left[i], leaf_size, first, last, leaf_box, node_box, lb);
+    r.right = lbvh_child_ref(right[i], leaf_size, first, last, leaf_box, node_box, rb);
+    for (int a = 0; a < 3; ++a) r.lmin[a] = lb[a], r.lmax[a] = lb[3 + a], r.rmin[a] = rb[a], r.rmax[a] = rb[3 + a];
+    r.pad0 = r.pad1 = 0;
+    inner[i] = r;
+}
+
+// TriRecord / AttrRecord of sorted position `slot` (leaf order), as bvh_build.cpp's flatten writes them
+__global__ void k_lbvh_emit_tris(int n, const uint32_t *__restrict__ ids, const float *__restrict__ pos,
+                                 const float *__restrict__ nrm, const float *__restrict__ uv, TriRecord *__restrict__ tris,
+                                 AttrRecord *__restrict__ attrs) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t t = ids[slot];
+    const float *p = pos + (size_t)t * 9, *q = nrm + (size_t)t * 9;
+    TriRecord tr;
+    for (int a = 0; a < 3; ++a) {
+        tr.v0[a] = p[a];
+        tr.e1[a] = p[3 + a] - p[a];  // triangle.cpp:12
+        tr.e2[a] = p[6 + a] - p[a];  // triangle.cpp:13
+    }
+    tr.id = t, tr.pad[0] = tr.pad[1] = 0;
+    tris[slot] = tr;
+    AttrRecord ar;
+    for (int a = 0; a < 3; ++a) ar.n0[a] = q[a], ar.n1[a] = q[3 + a], ar.n2[a] = q[6 + a];
+    for (int a = 0; a < 2; ++a) {
+        ar.uv0[a] = uv ? uv[(size_t)t * 6 + a] : 0.f;
+        ar.uv1[a] = uv ? uv[(size_t)t * 6 + 2 + a] : 0.f;
+        ar.uv2[a] = uv ? uv[(size_t)t * 6 + 4 + a] : 0.f;
+    }
+    ar.pad = 0.f;
+    attrs[slot] = ar;
+}
+
+// centroid bounds on the device: one block-level min/max + 6 float atomics per block (values are
+// order-independent, so the result is deterministic)
+__global__ void k_lbvh_bounds(const float *__restrict__ pos, uint32_t n, int *__restrict__ bounds /* keys of lo[3], hi[3] */) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t t = 0; t < ntris; ++t) {
-        const float *p = pos + (size_t)t * 9;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float *p = pos + (size_t)i * 9;
         for (int a = 0; a < 3; ++a) {
             const float c = ((p[a] + p[3 + a]) + p[6 + a]) * (1.f / 3.f);
             lo[a] = fminf(lo[a], c), hi[a] = fmaxf(hi[a], c);
         }
     }
-    float sc[3];
-    for (int a = 0; a < 3; ++a) sc[a] = hi[a] > lo[a] ? 2097151.f / (hi[a] - lo[a]) : 0.f;
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
+        }
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        for (int a = 0; a < 3; ++a) {
+            // float min/max through integer atomics on the order-preserving key (centroids are finite)
+            atomicMin(&bounds[a], __float_as_int(lo[a]) >= 0 ? __float_as_int(lo[a]) : (int)(0x80000000u - (uint32_t)__float_as_int(lo[a])));
+            atomicMax(&bounds[3 + a], __float_as_int(hi[a]) >= 0 ? __float_as_int(hi[a]) : (int)(0x80000000u - (uint32_t)__float_as_int(hi[a])));
+        }
+    }
+}
 
-    Buf<float> d_pos, d_leaf_box, d_node_box;
-    Buf<unsigned long long> d_keys, d_keys2;
-    Buf<uint32_t> d_ids, d_ids2, d_left, d_right, d_first, d_last, d_pint, d_pleaf, d_height;
-    Buf<unsigned int> d_arr;
-    Buf<unsigned char> d_tmp;
+__global__ void k_lbvh_keys(const float *__restrict__ pos, uint32_t n, const int *__restrict__ bounds_key,
+                                unsigned long long *__restrict__ keys, uint32_t *__restrict__ ids) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], sc[3];
+    for (int a = 0; a < 3; ++a) {
+        const int kl = bounds_key[a], kh = bounds_key[3 + a];
+        const float l = __int_as_float(kl >= 0 ? kl : (int)(0x80000000u - (uint32_t)kl));
+        const float h = __int_as_float(kh >= 0 ? kh : (int)(0x80000000u - (uint32_t)kh));
+        lo[a] = l;
+        sc[a] = h > l ? 2097151.f / (h - l) : 0.f;
+    }
+    const float *p = pos + (size_t)i * 9;
+    const float cx = ((p[0] + p[3]) + p[6]) * (1.f / 3.f), cy = ((p[1] + p[4]) + p[7]) * (1.f / 3.f),
+                cz = ((p[2] + p[5]) + p[8]) * (1.f / 3.f);
+    const uint32_t qx = (uint32_t)fminf(fmaxf((cx - lo[0]) * sc[0], 0.f), 2097151.f);
+    const uint32_t qy = (uint32_t)fminf(fmaxf((cy - lo[1]) * sc[1], 0.f), 2097151.f);
+    const uint32_t qz = (uint32_t)fminf(fmaxf((cz - lo[2]) * sc[2], 0.f), 2097151.f);
+    keys[i] = spread21(qx) << 2 | spread21(qy) << 1 | spread21(qz);
+    ids[i] = i;
+}
+
+template <class T>
+T *carve(unsigned char *&cursor, size_t count) {
+    T *p = (T *)cursor;
+    cursor += (count * sizeof(T) + 255) & ~(size_t)255;
+    return p;
+}
+
+}  // namespace
+
+void lbvh_release(LbvhDevice &d) {
+    if (d.arena) (void)hipFree(d.arena);
+    if (d.geom) (void)hipFree(d.geom);
+    if (d.attrs) (void)hipFree(d.attrs);
+    d = LbvhDevice{};
+}
+
+// The whole build on the device: upload -> Morton keys -> radix sort -> Karras hierarchy -> bottom-up fit ->
+// InnerRecord / TriRecord / AttrRecord emission.  Nothing comes back to the host except the root's height
+// (for the traversal stack depth); the hierarchy arrays stay in `out.arena` for lbvh_export_flat.
+bool build_bvh_lbvh_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
+                           int device, LbvhDevice &out, std::string &err) {
+    if (!check_bvh_input(pos, nrm, ntris, leaf_size, err)) return false;
+    const int n = (int)ntris;
     const size_t ni = n > 1 ? (size_t)n - 1 : 1;
-    LB_TRY(d_pos.alloc((size_t)n * 9));
-    LB_TRY(d_keys.alloc(n));
-    LB_TRY(d_keys2.alloc(n));
-    LB_TRY(d_ids.alloc(n));
-    LB_TRY(d_ids2.alloc(n));
-    LB_TRY(d_left.alloc(ni));
-    LB_TRY(d_right.alloc(ni));
-    LB_TRY(d_first.alloc(ni));
-    LB_TRY(d_last.alloc(ni));
-    LB_TRY(d_pint.alloc(ni));
-    LB_TRY(d_pleaf.alloc(n));
-    LB_TRY(d_height.alloc(ni));
-    LB_TRY(d_arr.alloc(ni));
-    LB_TRY(d_leaf_box.alloc((size_t)n * 6));
-    LB_TRY(d_node_box.alloc(ni * 6));
-    LB_TRY(hipMemcpy(d_pos.p, pos, (size_t)n * 36, hipMemcpyHostToDevice));
-    LB_TRY(hipMemset(d_arr.p, 0, ni * 4));
-    LB_TRY(hipMemset(d_height.p, 0, ni * 4));
+    LB_TRY(hipSetDevice(device));
+    out = LbvhDevice{};
+    out.ntris = ntris, out.leaf_size = leaf_size, out.n_inner = (uint32_t)ni;
+    size_t tmp_bytes = 0;
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                              (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 63));
+    // one arena for inputs, temporaries and the hierarchy (a hipMalloc per array costs more than the kernels)
+    const size_t in_floats = (size_t)n * (uv ? 24 : 18);
+    size_t arena_bytes = 0;
+    auto add = [&](size_t bytes) { arena_bytes += (bytes + 255) & ~(size_t)255; };
+    add(in_floats * 4), add((size_t)n * 8), add((size_t)n * 8), add((size_t)n * 4), add((size_t)n * 4);  // inputs, keys x2, ids x2
+    for (int k = 0; k < 6; ++k) add(ni * 4);                                                             // left right first last pint height
+    add((size_t)n * 4), add(ni * 4), add((size_t)n * 24), add(ni * 24), add(256), add(tmp_bytes);        // pleaf arrivals leaf_box node_box bounds tmp
+    LB_TRY(hipMalloc(&out.arena, arena_bytes));
+    out.arena_bytes = arena_bytes;
+    unsigned char *cur = (unsigned char *)out.arena;
+    float *d_in = carve<float>(cur, in_floats);
+    float *d_pos = d_in, *d_nrm = d_in + (size_t)n * 9, *d_uv = uv ? d_in + (size_t)n * 18 : nullptr;
+    unsigned long long *d_keys = carve<unsigned long long>(cur, n), *d_keys2 = carve<unsigned long long>(cur, n);
+    uint32_t *d_ids = carve<uint32_t>(cur, n);
+    out.ids = carve<uint32_t>(cur, n);
+    out.left = carve<uint32_t>(cur, ni), out.right = carve<uint32_t>(cur, ni);
+    out.first = carve<uint32_t>(cur, ni), out.last = carve<uint32_t>(cur, ni);
+    uint32_t *d_pint = carve<uint32_t>(cur, ni), *d_height = carve<uint32_t>(cur, ni);
+    uint32_t *d_pleaf = carve<uint32_t>(cur, n);
+    unsigned int *d_arr = carve<unsigned int>(cur, ni);
+    out.leaf_box = carve<float>(cur, (size_t)n * 6), out.node_box = carve<float>(cur, ni * 6);
+    int *d_bounds = carve<int>(cur, 64);
+    unsigned char *d_tmp = carve<unsigned char>(cur, tmp_bytes);
+
+    const size_t inner_bytes = ni * sizeof(InnerRecord), tri_bytes = (size_t)n * sizeof(TriRecord);
+    if (inner_bytes + tri_bytes + 64 > 0xFFFFFFFFull) {
+        err = "scene too large for 32-bit record offsets";
+        return false;
+    }
+    LB_TRY(hipMalloc(&out.geom, inner_bytes + tri_bytes + 64));
+    LB_TRY(hipMalloc(&out.attrs, (size_t)n * sizeof(AttrRecord)));
+    out.geom_bytes = inner_bytes + tri_bytes + 64, out.tri_off = (uint32_t)inner_bytes;
+
+    hipStream_t s = 0;
+    LB_TRY(hipMemcpyAsync(d_pos, pos, (size_t)n * 36, hipMemcpyHostToDevice, s));
+    LB_TRY(hipMemcpyAsync(d_nrm, nrm, (size_t)n * 36, hipMemcpyHostToDevice, s));
+    if (uv) LB_TRY(hipMemcpyAsync(d_uv, uv, (size_t)n * 24, hipMemcpyHostToDevice, s));
+    LB_TRY(hipMemsetAsync(d_arr, 0, ni * 4, s));
+    LB_TRY(hipMemsetAsync(d_height, 0, ni * 4, s));
+    LB_TRY(hipMemsetAsync((unsigned char *)out.geom + inner_bytes + tri_bytes, 0, 64, s));
+    const int init_bounds[6] = {0x7F800000, 0x7F800000, 0x7F800000, (int)0x80800000u, (int)0x80800000u, (int)0x80800000u};  // keys of +inf / -inf
+    LB_TRY(hipMemcpyAsync(d_bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, s));
 
     const dim3 blk(256), grd((n + 255) / 256);
-    hipLaunchKernelGGL(k_lbvh_keys, grd, blk, 0, 0, d_pos.p, ntris, lo[0], lo[1], lo[2], sc[0], sc[1], sc[2], d_keys.p,
-                       d_ids.p);
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min(1024, (n + 255) / 256)), blk, 0, s, d_pos, ntris, d_bounds);
+    hipLaunchKernelGGL(k_lbvh_keys, grd, blk, 0, s, d_pos, ntris, d_bounds, d_keys, d_ids);
     LB_TRY(hipGetLastError());
-    size_t tmp_bytes = 0;
-    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.p, d_keys2.p, d_ids.p, d_ids2.p, n, 0, 63));
-    LB_TRY(d_tmp.alloc(tmp_bytes));
-    LB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, d_ids.p, d_ids2.p, n, 0, 63));
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_ids, out.ids, n, 0, 63, s));
     if (n > 1) {
-        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n - 1 + 255) / 256), blk, 0, 0, d_keys2.p, n, d_left.p, d_right.p,
-                           d_first.p, d_last.p, d_pint.p, d_pleaf.p);
+        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n - 1 + 255) / 256), blk, 0, s, d_keys2, n, out.left, out.right,
+                           out.first, out.last, d_pint, d_pleaf);
         LB_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, 0, d_pos.p, d_ids2.p, n, d_left.p, d_right.p, d_pint.p, d_pleaf.p,
-                       d_leaf_box.p, d_node_box.p, d_height.p, d_arr.p);
+    hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, s, d_pos, out.ids, n, out.left, out.right, d_pint, d_pleaf, out.leaf_box,
+                       out.node_box, d_height, d_arr);
+    if (n > 1)
+        hipLaunchKernelGGL(k_lbvh_emit_inner, dim3((n - 1 + 255) / 256), blk, 0, s, n, leaf_size, out.left, out.right,
+                           out.first, out.last, out.leaf_box, out.node_box, (InnerRecord *)out.geom);
+    else
+        LB_TRY(hipMemsetAsync(out.geom, 0, sizeof(InnerRecord), s));
+    hipLaunchKernelGGL(k_lbvh_emit_tris, grd, blk, 0, s, n, out.ids, d_pos, d_nrm, d_uv,
+                       (TriRecord *)((unsigned char *)out.geom + inner_bytes), (AttrRecord *)out.attrs);
     LB_TRY(hipGetLastError());
-    LB_TRY(hipDeviceSynchronize());
+    uint32_t h = 0;
+    if (n > 1) LB_TRY(hipMemcpyAsync(&h, d_height, 4, hipMemcpyDeviceToHost, s));
+    LB_TRY(hipStreamSynchronize(s));
+    out.height = h;  // edges from the root to the deepest primitive: an upper bound of the collapsed tree's depth
+    if (out.height + 2 > kMaxStack) {
+        err = "BVH deeper than the reference's 64-entry traversal stack (bvh.cpp:54)";
+        return false;
+    }
+    out.root_ref = ntris <= leaf_size ? (kLeafBit | (ntris << kLeafCountShift)) : 0u;
+    return true;
+}
 
+// The reference's flat layout (bvh.h:11-14) of a device-built tree, for vmx_scene_bvh / vmx_scene_describe:
+// downloads the hierarchy and walks it depth first (pre-order, left child = i + 1); subtrees of at most
+// leaf_size triangles become leaves — the same collapse rule as k_lbvh_emit_inner.
+bool lbvh_export_flat(const LbvhDevice &d, int device, HostBvh &out, std::string &err) {
+    LB_TRY(hipSetDevice(device));
+    const int n = (int)d.ntris;
+    const size_t ni = n > 1 ? (size_t)n - 1 : 1;
     std::vector<uint32_t> left(ni), right(ni), first(ni), last(ni);
     std::vector<float> node_box(ni * 6), leaf_box((size_t)n * 6);
     out.prim_order.resize(n);
-    LB_TRY(hipMemcpy(out.prim_order.data(), d_ids2.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    LB_TRY(hipMemcpy(leaf_box.data(), d_leaf_box.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    LB_TRY(hipMemcpy(out.prim_order.data(), d.ids, (size_t)n * 4, hipMemcpyDeviceToHost));
+    LB_TRY(hipMemcpy(leaf_box.data(), d.leaf_box, (size_t)n * 24, hipMemcpyDeviceToHost));
     if (n > 1) {
-        LB_TRY(hipMemcpy(left.data(), d_left.p, ni * 4, hipMemcpyDeviceToHost));
-        LB_TRY(hipMemcpy(right.data(), d_right.p, ni * 4, hipMemcpyDeviceToHost));
-        LB_TRY(hipMemcpy(first.data(), d_first.p, ni * 4, hipMemcpyDeviceToHost));
-        LB_TRY(hipMemcpy(last.data(), d_last.p, ni * 4, hipMemcpyDeviceToHost));
-        LB_TRY(hipMemcpy(node_box.data(), d_node_box.p, ni * 24, hipMemcpyDeviceToHost));
+        LB_TRY(hipMemcpy(left.data(), d.left, ni * 4, hipMemcpyDeviceToHost));
+        LB_TRY(hipMemcpy(right.data(), d.right, ni * 4, hipMemcpyDeviceToHost));
+        LB_TRY(hipMemcpy(first.data(), d.first, ni * 4, hipMemcpyDeviceToHost));
+        LB_TRY(hipMemcpy(last.data(), d.last, ni * 4, hipMemcpyDeviceToHost));
+        LB_TRY(hipMemcpy(node_box.data(), d.node_box, ni * 24, hipMemcpyDeviceToHost));
     }
-
-    // depth-first walk into the reference's flat layout; subtrees of <= leaf_size triangles become leaves
     out.start.clear(), out.nprims.clear(), out.right_offset.clear(), out.bbox.clear();
     out.n_leaves = 0, out.max_depth = 0;
     struct Item {
@@ -241,7 +395,7 @@ bool build_bvh_lbvh(const float *pos, const float *nrm, const float *uv, uint32_
         const uint32_t idx = it.child & 0x7FFFFFFFu;
         const uint32_t begin = is_prim ? idx : first[idx], end = is_prim ? idx + 1 : last[idx] + 1;
         const float *box = is_prim ? &leaf_box[(size_t)idx * 6] : &node_box[(size_t)idx * 6];
-        const bool leaf = end - begin <= leaf_size;
+        const bool leaf = end - begin <= d.leaf_size;
         out.start.push_back(begin);
         out.nprims.push_back(end - begin);
         out.right_offset.push_back(leaf ? 0u : 0xffffffffu);
@@ -255,7 +409,7 @@ bool build_bvh_lbvh(const float *pos, const float *nrm, const float *uv, uint32_
         work.push_back({right[idx], me, it.depth + 1, true});  // popped after the whole left subtree
         work.push_back({left[idx], me, it.depth + 1, false});
     }
-    return flatten_bvh(pos, nrm, uv, ntris, out, err);
+    return true;
 }
 
 }  // namespace vmx

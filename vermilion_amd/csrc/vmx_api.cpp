@@ -133,7 +133,10 @@ struct Workspace {
 struct vmx_scene {
     int device = 0;
     int num_cus = 0;
-    HostBvh bvh;
+    HostBvh bvh;        // host-built trees: flat layout + device records; device-built (LBVH): filled on demand
+    LbvhDevice lbvh;    // VMX_BVH_LBVH: the tree was built and flattened on the device (lbvh_build.hip)
+    bool device_built = false, flat_ready = true;
+    uint32_t n_inner = 0;  // inner record slots on the device
     uint32_t ntris = 0, leaf_size = 4;
     std::vector<vmx_sphere> spheres;
     // inner records, then (64-byte aligned) the triangle records, in ONE allocation: a lane of the bounce
@@ -595,10 +598,10 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     HIP_TRY(hipEventRecord(ev0, s));
     if (split_any) {
         // camera-relative copies of the node and triangle records for this frame's origin
-        const size_t n_inner = std::max<size_t>(sc->bvh.inner.size(), 1);
+        const size_t n_inner = std::max<size_t>(sc->n_inner, 1);
         if (ws.cam_inner.ensure(n_inner * 64 * 8) || ws.cam_tris.ensure((size_t)sc->ntris * 64))
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the camera tables");
-        LAUNCH_TRY(launch_camera_tables(sc->dev, (uint32_t)sc->bvh.inner.size(), fr.px, fr.py, fr.pz, ws.cam_inner.p,
+        LAUNCH_TRY(launch_camera_tables(sc->dev, sc->n_inner, fr.px, fr.py, fr.pz, ws.cam_inner.p,
                                         ws.cam_tris.p, s));
         launches++;
     }
@@ -674,7 +677,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.band_items = wk.band_slots * S;
             wk.pixel_major = 1;
             wk.cam_inner = ws.cam_inner.p, wk.cam_tris = ws.cam_tris.p;
-            wk.cam_n_inner = (uint32_t)sc->bvh.inner.size();
+            wk.cam_n_inner = sc->n_inner;
             LaunchCfg cfg = paths_cfg(sc, tn.lds_primary, (uint64_t)n_pad * S, tb);
             rc = bind_stack(sc, tn, tn.lds_primary, cfg.grid, wk);
             if (rc) return rc;
@@ -802,27 +805,41 @@ static int scene_upload(vmx_scene *sc) {
         d.nsign = s.normal_sign < 0.f ? -1.f : 1.f;
         d.flags = s.flags;
     }
-    const HostBvh &b = sc->bvh;
-    const size_t inner_bytes = std::max<size_t>(b.inner.size(), 1) * sizeof(InnerRecord);
-    const size_t tri_bytes = b.tris.size() * sizeof(TriRecord);
-    if (inner_bytes + tri_bytes + 64 > 0xFFFFFFFFull) return fail(VMX_ERR_INVALID, "scene too large for 32-bit record offsets");
-    if (sc->d_geom.ensure(inner_bytes + tri_bytes + 64) ||
-        sc->d_attrs.ensure(b.attrs.size()) || sc->d_spheres.ensure(std::max<size_t>(sd.size(), 1)))
-        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the scene");
-    HIP_TRY(hipMemset(sc->d_geom.p, 0, inner_bytes + tri_bytes + 64));
-    if (b.inner.size()) HIP_TRY(hipMemcpy(sc->d_geom.p, b.inner.data(), b.inner.size() * sizeof(InnerRecord), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(sc->d_geom.p + inner_bytes, b.tris.data(), tri_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(sc->d_attrs.p, b.attrs.data(), b.attrs.size() * sizeof(AttrRecord), hipMemcpyHostToDevice));
+    if (sc->d_spheres.ensure(std::max<size_t>(sd.size(), 1))) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the scene");
     if (sd.size()) HIP_TRY(hipMemcpy(sc->d_spheres.p, sd.data(), sd.size() * sizeof(SphereDev), hipMemcpyHostToDevice));
-    sc->dev.inner = sc->d_geom.p;
-    sc->dev.tris = sc->d_geom.p + inner_bytes;
-    sc->dev.tri_off = (uint32_t)inner_bytes;
-    sc->dev.attrs = sc->d_attrs.p;
     sc->dev.spheres = sc->d_spheres.p;
-    sc->dev.root_ref = b.root_ref;
     sc->dev.nspheres = (uint32_t)sd.size();
-    sc->dev.stack_entries = b.max_depth + 2;
     sc->dev.ntris = sc->ntris;
+    if (sc->device_built) {
+        // records were written on the device (k_lbvh_emit_*): the scene takes the builder's buffers over
+        const LbvhDevice &l = sc->lbvh;
+        sc->dev.inner = l.geom;
+        sc->dev.tris = (const unsigned char *)l.geom + l.tri_off;
+        sc->dev.tri_off = l.tri_off;
+        sc->dev.attrs = l.attrs;
+        sc->dev.root_ref = l.root_ref;
+        sc->dev.stack_entries = l.height + 2;
+        sc->n_inner = l.n_inner;
+    } else {
+        const HostBvh &b = sc->bvh;
+        const size_t inner_bytes = std::max<size_t>(b.inner.size(), 1) * sizeof(InnerRecord);
+        const size_t tri_bytes = b.tris.size() * sizeof(TriRecord);
+        // + 64: the quad-cooperative fetch reads 64 bytes from a 48-byte triangle record's start
+        if (inner_bytes + tri_bytes + 64 > 0xFFFFFFFFull) return fail(VMX_ERR_INVALID, "scene too large for 32-bit record offsets");
+        if (sc->d_geom.ensure(inner_bytes + tri_bytes + 64) || sc->d_attrs.ensure(b.attrs.size()))
+            return fail(VMX_ERR_NOMEM, "hipMalloc failed for the scene");
+        HIP_TRY(hipMemset(sc->d_geom.p, 0, inner_bytes + tri_bytes + 64));
+        if (b.inner.size()) HIP_TRY(hipMemcpy(sc->d_geom.p, b.inner.data(), b.inner.size() * sizeof(InnerRecord), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sc->d_geom.p + inner_bytes, b.tris.data(), tri_bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(sc->d_attrs.p, b.attrs.data(), b.attrs.size() * sizeof(AttrRecord), hipMemcpyHostToDevice));
+        sc->dev.inner = sc->d_geom.p;
+        sc->dev.tris = sc->d_geom.p + inner_bytes;
+        sc->dev.tri_off = (uint32_t)inner_bytes;
+        sc->dev.attrs = sc->d_attrs.p;
+        sc->dev.root_ref = b.root_ref;
+        sc->dev.stack_entries = b.max_depth + 2;
+        sc->n_inner = (uint32_t)b.inner.size();
+    }
     // LDS budget: shrink the block until one block's stacks fit in 64 KiB
     sc->block = 256;
     while (sc->block > 64 && (sc->block / 64) * sc->dev.stack_entries * 512 > 65536) sc->block /= 2;
@@ -849,10 +866,16 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
     sc->ntris = ntris;
     sc->leaf_size = leaf_size ? leaf_size : 4;
     std::string err;
-    const bool built = builder == VMX_BVH_SAH    ? build_bvh_sah(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err)
-                       : builder == VMX_BVH_LBVH ? build_bvh_lbvh(pos, nrm, uv, ntris, sc->leaf_size, device, sc->bvh, err)
-                                                 : build_bvh(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err);
+    bool built;
+    if (builder == VMX_BVH_LBVH) {
+        sc->device_built = true, sc->flat_ready = false;
+        built = build_bvh_lbvh_device(pos, nrm, uv, ntris, sc->leaf_size, device, sc->lbvh, err);
+    } else {
+        built = builder == VMX_BVH_SAH ? build_bvh_sah(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err)
+                                       : build_bvh(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err);
+    }
     if (!built) {
+        lbvh_release(sc->lbvh);
         const int code = err.find("deeper") != std::string::npos ? VMX_ERR_DEPTH : VMX_ERR_INVALID;
         delete sc;
         return fail(code, err);
@@ -876,6 +899,7 @@ int vmx_scene_destroy(vmx_scene *sc) {
     (void)hipSetDevice(sc->device);
     sc->ws.release();
     sc->d_geom.release(), sc->d_attrs.release(), sc->d_spheres.release();
+    lbvh_release(sc->lbvh);
     sc->d_tex.release(), sc->d_tex1.release();
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
@@ -906,19 +930,32 @@ int vmx_scene_bind_texture(vmx_scene *sc, const float *data, uint32_t width, uin
     return VMX_OK;
 }
 
+// device-built trees: the reference's flat layout is produced on the first request for it
+static int ensure_flat(const vmx_scene *csc) {
+    vmx_scene *sc = const_cast<vmx_scene *>(csc);
+    if (sc->flat_ready) return VMX_OK;
+    std::lock_guard<std::mutex> lock(sc->mu);
+    if (sc->flat_ready) return VMX_OK;
+    std::string err;
+    if (!lbvh_export_flat(sc->lbvh, sc->device, sc->bvh, err)) return fail(VMX_ERR_HIP, err);
+    sc->flat_ready = true;
+    return VMX_OK;
+}
+
 int vmx_scene_describe(const vmx_scene *sc, vmx_scene_desc *out) {
     if (!sc || !out) return fail(VMX_ERR_INVALID, "NULL argument");
+    if (int rc = ensure_flat(sc)) return rc;
     std::memset(out, 0, sizeof(*out));
     out->ntris = sc->ntris;
     out->nspheres = (uint32_t)sc->spheres.size();
     out->leaf_size = sc->leaf_size;
     out->n_nodes = (uint32_t)sc->bvh.start.size();
     out->n_leaves = sc->bvh.n_leaves;
-    out->n_inner = (uint32_t)sc->bvh.inner.size();
+    out->n_inner = sc->n_inner;
     out->max_depth = sc->bvh.max_depth;
     out->stack_entries = sc->dev.stack_entries;
-    out->device_bytes = sc->bvh.inner.size() * sizeof(InnerRecord) + sc->bvh.tris.size() * sizeof(TriRecord) +
-                        sc->bvh.attrs.size() * sizeof(AttrRecord) + sc->spheres.size() * sizeof(SphereDev);
+    out->device_bytes = (size_t)sc->n_inner * sizeof(InnerRecord) + (size_t)sc->ntris * sizeof(TriRecord) +
+                        (size_t)sc->ntris * sizeof(AttrRecord) + sc->spheres.size() * sizeof(SphereDev);
     out->device = sc->device;
     return VMX_OK;
 }
@@ -932,6 +969,7 @@ int vmx_scene_timings(const vmx_scene *sc, vmx_timings *out) {
 int vmx_scene_bvh(const vmx_scene *sc, uint32_t *start, uint32_t *nprims, uint32_t *right_offset, float *bbox,
                   uint32_t *prim_order) {
     if (!sc) return fail(VMX_ERR_INVALID, "NULL scene");
+    if (int rc = ensure_flat(sc)) return rc;
     const HostBvh &b = sc->bvh;
     const size_t n = b.start.size();
     if (start) std::memcpy(start, b.start.data(), n * 4);
@@ -1355,17 +1393,28 @@ int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32
             vmx_multi_destroy(m);
             return fail(VMX_ERR_NO_DEVICE, "device ordinal out of range");
         }
-        vmx_scene *sc = new vmx_scene();  // replica: shares the host-side build, uploads to its own device
-        sc->device = devices[i];
-        sc->ntris = first->ntris, sc->leaf_size = first->leaf_size;
-        sc->bvh = first->bvh;
-        sc->spheres = first->spheres;
-        rc = scene_upload(sc);
-        if (rc) {
-            const std::string keep = g_err;
-            vmx_scene_destroy(sc);
-            vmx_multi_destroy(m);
-            return fail(rc, keep);
+        vmx_scene *sc = nullptr;
+        if (first->device_built) {
+            // a device-built tree is built again on every device (deterministic: same sort, same boxes)
+            rc = vmx_scene_create_ex(pos, nrm, uv, ntris, spheres, nspheres, leaf_size, builder, devices[i], &sc);
+            if (rc) {
+                const std::string keep = g_err;
+                vmx_multi_destroy(m);
+                return fail(rc, keep);
+            }
+        } else {
+            sc = new vmx_scene();  // replica: shares the host-side build, uploads to its own device
+            sc->device = devices[i];
+            sc->ntris = first->ntris, sc->leaf_size = first->leaf_size;
+            sc->bvh = first->bvh;
+            sc->spheres = first->spheres;
+            rc = scene_upload(sc);
+            if (rc) {
+                const std::string keep = g_err;
+                vmx_scene_destroy(sc);
+                vmx_multi_destroy(m);
+                return fail(rc, keep);
+            }
         }
         m->replica.push_back(sc);
         // direct peer copies into the root's gather buffer (xGMI); without peer access the runtime stages
