@@ -637,7 +637,10 @@ __device__ __forceinline__ bool path_shade(const SceneDev &sc, float r2scale, Pa
     ShadeMid m;
     const int st = path_shade_begin<TEX>(sc, r2scale, P, c, fl, m);
     if (st != kPathNeedsTrig) return st == kPathNextRay;
-    return path_shade_end(P, c, fl, m, (float)cos(m.angle), (float)sin(m.angle));
+    // one range reduction for both (sincos returns exactly sin and cos: same kernels; the frame tests would show)
+    double sn, cs;
+    sincos(m.angle, &sn, &cs);
+    return path_shade_end(P, c, fl, m, (float)cs, (float)sn);
 }
 
 template <bool COUNT>
@@ -2157,7 +2160,11 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
         bool alive = st == kPathNextRay;
         // (gathering the block's ~10 % of angles in LDS to evaluate cos/sin in full waves was measured:
         // the three barriers it needs cost what it saves)
-        if (st == kPathNeedsTrig) alive = path_shade_end(P, c, fl, mid, (float)cos(mid.angle), (float)sin(mid.angle));
+        if (st == kPathNeedsTrig) {
+            double sn, cs;
+            sincos(mid.angle, &sn, &cs);  // one range reduction for both; bit-identical to cos() and sin()
+            alive = path_shade_end(P, c, fl, mid, (float)cs, (float)sn);
+        }
         if (alive) {
             ray_store(pa, pid, P);
             rng_store(pa, pid, P.rng);
