@@ -15,6 +15,7 @@ gather and assembly are inside the timed step.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -120,11 +121,16 @@ def main():
         torch.cuda.synchronize(dev)
 
     def timed(k, **kw):
+        # (a generation-2 Python garbage collection inside a timed region showed up as +36 ms on the three
+        # early-stop frames whenever --steps happened to place it there: collect first, keep it out)
+        gc.collect()
+        gc.disable()
         sync()
         t0 = time.perf_counter()
         stats = [step(**kw)[0] for _ in range(k)]
         sync()
         dt = time.perf_counter() - t0
+        gc.enable()
         rays = float(sum(s["rays_primary"] + s["rays_secondary"] for s in stats))
         if world > 1:
             rdev = dev if args.backend == "nccl" else torch.device("cpu")
