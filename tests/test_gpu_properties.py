@@ -181,3 +181,20 @@ def test_config5_stripes_of_the_4k_1024spp_frame(sponza):
         part, sp = sponza.render(cam, va.make_opts(seed=8, early_stop=False, rank=r, world=8, stripe_rows=16))
         assert np.array_equal(bits(part), bits(full[va.local_row_indices(H, 16, r, 8)]))
         assert sp["samples"] == part.shape[0] * W * spp
+
+
+def test_per_kernel_timings_of_the_last_render(sponza):
+    """vmx_scene_timings: what bench.py's roofline object takes its launch durations from"""
+    cam = sponza_cam(480, 270, 64)
+    _, st = sponza.render(cam, va.make_opts(seed=2, early_stop=False, pipeline=4, tail_threshold=1))
+    t = sponza.timings()
+    for k in ("raygen", "trace_camera", "shade_camera", "trace_bounce", "shade_bounce", "resolve"):
+        assert t[k]["launches"] >= 1 and t[k]["ms"] > 0 and t[k]["longest_ms"] <= t[k]["ms"] + 1e-9, k
+    assert t["tail"]["launches"] == 0 and t["fused"]["launches"] == 0 and t["bruteforce"]["launches"] == 0
+    assert abs(t["trace_camera"]["ms"] - st["primary"]["ms"]) < 1e-6
+    assert abs(t["trace_bounce"]["ms"] + t["tail"]["ms"] - st["bounce"]["ms"]) < 1e-6
+    _, st2 = sponza.render(cam, va.make_opts(seed=2, early_stop=False, pipeline=1))
+    t2 = sponza.timings()
+    assert t2["fused"]["launches"] >= 1 and t2["trace_camera"]["launches"] == 0
+    _, _ = sponza.render_bruteforce(sponza_cam(96, 64, 8), va.make_opts(seed=2))
+    assert sponza.timings()["bruteforce"]["launches"] == 1
