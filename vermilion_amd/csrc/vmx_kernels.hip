@@ -1771,12 +1771,50 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 //   * the all-lanes-idle test is made once per 8 steps, not every step.
 // Each ray still performs exactly the reference's sequence of tests (bvh.cpp:47-145).
 // ---------------------------------------------------------------------------
+#ifdef VMX_STEP_PROFILE
+// Diagnostic build only (tools/step_profile.py; make EXTRA=-DVMX_STEP_PROFILE): wave-cycles and wave-steps of
+// k_trace_w by the state in which the wave enters a step.  [SRC][category][0 = cycles, 1 = steps]; categories:
+// 0 every traversing lane at the same inner node, 1 inner nodes only (not all the same), 2 leaves only,
+// 3 inner nodes and leaves, 4 no traversing lane, 5 refill section, 6 steps of NaN-exact batches
+__device__ unsigned long long g_step_prof[2][8][2];
+extern "C" int vmx_debug_step_profile(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_prof), sizeof(g_step_prof)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zero[2][8][2];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_step_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define VMX_PROF_STEP(EX, OC)                                                                                   \
+    do {                                                                                                        \
+        const unsigned long long pt_ = __builtin_amdgcn_ballot_w64(cur != kIdle);                               \
+        const unsigned long long pl_ = __builtin_amdgcn_ballot_w64(cur != kIdle && (int)cur < 0);               \
+        const uint32_t pc0_ = (uint32_t)__builtin_amdgcn_readlane((int)cur, pt_ ? (int)__ffsll((long long)pt_) - 1 : 0); \
+        const bool pu_ = __builtin_amdgcn_ballot_w64(cur != kIdle && cur != pc0_) == 0;                         \
+        const uint32_t cat_ = decltype(EX)::value ? 6u : pt_ == 0 ? 4u : pl_ == pt_ ? 2u : pl_ != 0 ? 3u : pu_ ? 0u : 1u; \
+        const unsigned long long t0_ = __builtin_readcyclecounter();                                            \
+        step(EX, OC);                                                                                           \
+        const unsigned long long t1_ = __builtin_readcyclecounter();                                            \
+        if (lane == 0) {                                                                                        \
+            s_prof[wave][cat_][0] += t1_ - t0_;                                                                 \
+            s_prof[wave][cat_][1] += 1;                                                                         \
+        }                                                                                                       \
+    } while (0)
+#else
+#define VMX_PROF_STEP(EX, OC) step(EX, OC)
+#endif
+
 template <int SRC>
 __global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD)
 k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     extern __shared__ uint2 lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const int lds_entries = (int)wk.lds_entries;
+#ifdef VMX_STEP_PROFILE
+    __shared__ unsigned long long s_prof[4][8][2];
+    if (lane < 16) s_prof[wave][lane >> 1][lane & 1] = 0;
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     uint2 *stk = lds_stack + (size_t)wave * (lds_entries + 1) * 64 + lane;
     uint2 *ovf = (uint2 *)wk.overflow_stack +
                  ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * wk.overflow_entries) * 64 + lane;
@@ -2061,6 +2099,15 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             }
         }
         const unsigned long long active = __builtin_amdgcn_ballot_w64(cur != kIdle);
+#ifdef VMX_STEP_PROFILE
+        {
+            const unsigned long long now = __builtin_readcyclecounter();
+            if (lane == 0) {
+                s_prof[wave][5][0] += now - prof_t;
+                s_prof[wave][5][1] += 1;
+            }
+        }
+#endif
         if (active == 0) break;
         if (SRC == 0) {
             const uint32_t oct = (__float_as_uint(ix) >> 31) | ((__float_as_uint(iy) >> 31) << 1) |
@@ -2070,18 +2117,24 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         }
         if (__builtin_amdgcn_ballot_w64(exact && cur != kIdle) != 0) {
 #pragma unroll 1
-            for (int act = 0; act < 8; ++act) step(std::true_type{}, std::false_type{});
+            for (int act = 0; act < 8; ++act) VMX_PROF_STEP(std::true_type{}, std::false_type{});
         } else if (SRC == 0 && wave_octant < 8) {
             uni_base = (const char *)inner + (size_t)wave_octant * wk.cam_n_inner * 64;
             // (16 steps per batch here: these waves refill only when all 64 lanes are done; measured 8 / 16 / 32)
 #pragma unroll 1
-            for (int act = 0; act < 16; ++act) step(std::false_type{}, std::true_type{});
+            for (int act = 0; act < 16; ++act) VMX_PROF_STEP(std::false_type{}, std::true_type{});
         } else {
             uni_base = (const char *)inner;
 #pragma unroll 1
-            for (int act = 0; act < 8; ++act) step(std::false_type{}, std::false_type{});
+            for (int act = 0; act < 8; ++act) VMX_PROF_STEP(std::false_type{}, std::false_type{});
         }
+#ifdef VMX_STEP_PROFILE
+        prof_t = __builtin_readcyclecounter();
+#endif
     }
+#ifdef VMX_STEP_PROFILE
+    if (lane < 16) atomicAdd(&g_step_prof[SRC][lane >> 1][lane & 1], s_prof[wave][lane >> 1][lane & 1]);
+#endif
 }
 
 // ---------------------------------------------------------------------------
