@@ -25,10 +25,10 @@ sc.render_device(cam, o, out.data_ptr()); torch.cuda.synchronize()
 fn(buf.ctypes.data, 0)
 print({k: round(v["ms"], 2) for k, v in sc.timings().items() if v["launches"]})
 names = ["same inner node", "inner nodes, not all the same", "leaves only", "inner nodes and leaves", "no traversing lane",
-         "refill section", "NaN-exact batch"]
+         "refill section", "NaN-exact batch / same node, mixed octants", "uniform_descent (asm loop)"]
 for src, kn in enumerate(("k_trace_w<0> camera rays", "k_trace_w<1> bounce rays")):
     cyc, n = buf[src, :, 0].astype(float), buf[src, :, 1].astype(float)
-    print(f"---- {kn}: {cyc.sum() / 1e9:.2f} G wave-cycles, {n[:5].sum() / 1e6:.1f} M wave-steps")
+    print(f"---- {kn}: {cyc.sum() / 1e9:.2f} G wave-cycles, {(n[:5].sum() + n[6] + n[7]) / 1e6:.1f} M wave-steps")
     for i, nm in enumerate(names):
         if n[i]:
-            print(f"{nm:32s} {n[i] / 1e6:9.1f} M  {100 * n[i] / max(n[:5].sum() + n[6], 1):5.1f} % of steps   {cyc[i] / n[i]:8.0f} cycles each   {100 * cyc[i] / cyc.sum():5.1f} % of wave-time")
+            print(f"{nm:32s} {n[i] / 1e6:9.1f} M  {100 * n[i] / max(n[:5].sum() + n[6] + n[7], 1):5.1f} % of steps   {cyc[i] / n[i]:8.0f} cycles each   {100 * cyc[i] / cyc.sum():5.1f} % of wave-time")

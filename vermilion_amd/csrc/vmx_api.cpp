@@ -23,6 +23,10 @@
 #include "vmx_device.h"
 #include "vmx_kernels.h"
 
+#ifndef VMX_LDS_PRIMARY
+#define VMX_LDS_PRIMARY 8  // LDS stack levels of the camera-ray kernel (A/B builds: make EXTRA=-DVMX_LDS_PRIMARY=n)
+#endif
+
 using namespace vmx;
 
 namespace {
@@ -332,7 +336,7 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     // fetch it preferred 13 levels at 5-6 waves); the fused kernels keep 10 (7 waves).
     const uint32_t cap = o->reserved[6];
     tn.lds_entries = std::min(sc->dev.stack_entries, cap ? cap : 10u);
-    tn.lds_primary = std::min(sc->dev.stack_entries, cap ? cap : 8u);
+    tn.lds_primary = std::min(sc->dev.stack_entries, cap ? cap : (uint32_t)VMX_LDS_PRIMARY);
     tn.lds_bounce = std::min(sc->dev.stack_entries, cap ? cap : 9u);
     // bounce generations with fewer live paths than this finish in one fused launch (measured on the
     // Sponza stand-in: 512 K -> 16 M = 155.7 -> 152.9 ms fixed spp, 23.6 -> 20.8 ms with early stop)

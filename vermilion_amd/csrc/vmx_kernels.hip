@@ -1771,11 +1771,128 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 //   * the all-lanes-idle test is made once per 8 steps, not every step.
 // Each ray still performs exactly the reference's sequence of tests (bvh.cpp:47-145).
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// uniform_descent — camera rays: the stretch of a traversal in which all traversing lanes of a wave are at
+// the same inner node and take the same child, as one assembly loop.
+//
+// k_trace_w<0> is bound by instruction issue: on gfx950 a SIMD issues about one instruction per 2.2
+// cycles whatever its kind — scalar ALU instructions do not overlap with vector ones — and a taken
+// branch costs about three instructions (tools/sload_probe.hip, profiles/r02_sload_probe.txt); its
+// counters add up to exactly that ((SQ_INSTS_VALU + SQ_INSTS_SALU) x 2.15 cycles = the kernel's SIMD
+// cycles).  64 samples of one pixel walk the tree together, and the compiled step spends ~63
+// instructions and two taken branches on such a node (lane dispatch, uniformity test, exec-masked push,
+// lane masks merged with scalar ops) where the arithmetic is 16.  One iteration here is 39 instructions
+// and the back edge:
+//   * the 12 products and two max3/min3 pairs straight from the scalar-fetched record of the wave's
+//     octant copy (near planes first, as the OCT route of the general step);
+//   * a missed child gets the entry distance +inf, so "the right child is strictly closer, or the only
+//     one hit" is one compare, near/far are a min and a max, and `near > t` (bvh.cpp:69) prunes a missed
+//     child like a far one;
+//   * the other child is stored above the stack top by every lane (no exec mask) and counts as an entry
+//     (sp + 1) only where its distance is finite, i.e. where both children were hit (a child hit at +inf
+//     is treated as missed: the reference would pop it again unvisited, `inf > t`);
+//   * the next node is chosen on the scalar unit (s_cselect) and its record fetch issued at once.
+// While the lanes agree, none of them prunes and the next node is an inner node, the loop needs no
+// per-lane node reference, no exec masking and no refill test (no lane can finish here).  When lanes
+// disagree or one of them prunes, the node is finished per lane (same values, lane selects) and the
+// general step goes on from there; a leaf, or a lane whose next push would leave the LDS levels, ends the
+// loop as well.  Every ray performs exactly the tests of the general step, in the same order.
+//   in: trav = the traversing lanes, scur = the inner node they all are at, sp < lds_entries in each of them
+//   out: cur (per lane: next node, leaf or kPop), sp; returns the number of nodes done
+// The record lives in s[36:51] (an inline-asm operand cannot be a 16-register tuple).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, float ix, float iy, float iz, float best,
+                                                    uint32_t stk_lds, const char *base, uint32_t scur,
+                                                    int lds_entries, unsigned long long trav) {
+    float t0, t1, t2, n0, tf, n1, near, far;
+    uint32_t va, oth, soff, soth, done = 0;
+    unsigned long long tmp, pop;
+    asm volatile(
+        "s_mov_b64 exec, %[trav]\n\t"
+        "s_lshl_b32 %[soff], %[scur], 6\n\t"
+        "s_load_dwordx16 s[36:51], %[base], %[soff]\n"
+        "1:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f32_e32 %[t0], s36, %[ix]\n\t"
+        "v_mul_f32_e32 %[t1], s37, %[iy]\n\t"
+        "v_mul_f32_e32 %[t2], s38, %[iz]\n\t"
+        "v_max3_f32 %[n0], %[t0], %[t1], %[t2]\n\t"
+        "v_mul_f32_e32 %[t0], s39, %[ix]\n\t"
+        "v_mul_f32_e32 %[t1], s40, %[iy]\n\t"
+        "v_mul_f32_e32 %[t2], s41, %[iz]\n\t"
+        "v_min3_f32 %[tf], %[t0], %[t1], %[t2]\n\t"
+        "v_cmp_le_f32_e32 vcc, %[n0], %[tf]\n\t"              // left child hit (bbox.cpp:82)
+        "v_mul_f32_e32 %[t0], s42, %[ix]\n\t"
+        "v_mul_f32_e32 %[t1], s43, %[iy]\n\t"
+        "v_mul_f32_e32 %[t2], s44, %[iz]\n\t"
+        "v_cndmask_b32_e32 %[n0], %[inf], %[n0], vcc\n\t"  // its entry distance, +inf if missed
+        "v_max3_f32 %[n1], %[t0], %[t1], %[t2]\n\t"
+        "v_mul_f32_e32 %[t0], s45, %[ix]\n\t"
+        "v_mul_f32_e32 %[t1], s46, %[iy]\n\t"
+        "v_mul_f32_e32 %[t2], s47, %[iz]\n\t"
+        "v_min3_f32 %[tf], %[t0], %[t1], %[t2]\n\t"
+        "v_cmp_le_f32_e32 vcc, %[n1], %[tf]\n\t"              // right child hit
+        "s_add_u32 %[done], %[done], 1\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e32 %[n1], %[inf], %[n1], vcc\n\t"
+        "v_cmp_lt_f32_e32 vcc, %[n1], %[n0]\n\t"              // go right: strictly closer, or the only one hit (bvh.cpp:106)
+        "v_min_f32_e32 %[near], %[n0], %[n1]\n\t"
+        "v_max_f32_e32 %[far], %[n0], %[n1]\n\t"
+        "v_cmp_gt_f32_e64 %[pop], %[near], %[best]\n\t"       // the child taken is pruned, or none was hit (bvh.cpp:69)
+        "s_cmp_eq_u64 vcc, 0\n\t"                             // every lane goes left?
+        "s_cselect_b32 %[scur], s48, s49\n\t"
+        "s_cselect_b32 %[soth], s49, s48\n\t"
+        "s_cselect_b64 %[tmp], exec, vcc\n\t"
+        "s_andn2_b64 %[tmp], %[tmp], %[pop]\n\t"
+        "s_cmp_eq_u64 %[tmp], exec\n\t"                       // all lanes the same way and none prunes
+        "s_cbranch_scc0 2f\n\t"
+        "v_mov_b32_e32 %[oth], %[soth]\n\t"
+        "v_lshl_add_u32 %[va], %[sp], 9, %[stk]\n\t"
+        "ds_write2_b32 %[va], %[oth], %[far] offset1:1\n\t"   // the other child, above the top
+        "v_cmp_gt_f32_e32 vcc, %[inf], %[far]\n\t"        // ... an entry where both children were hit
+        "s_lshl_b32 %[soff], %[scur], 6\n\t"
+        "s_bitcmp1_b32 %[scur], 31\n\t"                       // the child taken is a leaf?
+        "v_addc_co_u32_e32 %[sp], vcc, 0, %[sp], vcc\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_load_dwordx16 s[36:51], %[base], %[soff]\n\t"
+        "v_cmp_le_i32_e32 vcc, %[lds], %[sp]\n\t"             // a lane whose next push would leave the LDS levels?
+        "s_cbranch_vccz 1b\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"                            // nothing may land in s[36:51] after the block
+        "s_branch 3f\n"
+        // ---- the lanes part ways here: finish this node per lane (bvh.cpp:103-132)
+        "2:\n\t"
+        "v_mov_b32_e32 %[t0], s48\n\t"
+        "v_mov_b32_e32 %[t1], s49\n\t"
+        "v_cndmask_b32_e32 %[oth], %[t1], %[t0], vcc\n\t"     // stored: go right ? left : right
+        "v_cndmask_b32_e32 %[t2], %[t0], %[t1], vcc\n\t"      // taken
+        "v_lshl_add_u32 %[va], %[sp], 9, %[stk]\n\t"
+        "ds_write2_b32 %[va], %[oth], %[far] offset1:1\n\t"
+        "v_mov_b32_e32 %[t0], 0x7ffffffd\n\t"
+        "v_cmp_gt_f32_e32 vcc, %[inf], %[far]\n\t"
+        "v_cndmask_b32_e64 %[cur], %[t2], %[t0], %[pop]\n\t"  // kPop where the lane prunes
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e32 %[sp], vcc, 0, %[sp], vcc\n\t"
+        "s_branch 4f\n"
+        "3:\n\t"
+        "v_mov_b32_e32 %[cur], %[scur]\n"
+        "4:\n\t"
+        "s_mov_b64 exec, -1"
+        : [sp] "+v"(sp), [cur] "+v"(cur), [scur] "+s"(scur), [done] "+s"(done), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [t2] "=&v"(t2), [n0] "=&v"(n0), [tf] "=&v"(tf), [n1] "=&v"(n1), [near] "=&v"(near), [far] "=&v"(far),
+          [va] "=&v"(va), [oth] "=&v"(oth), [soff] "=&s"(soff), [soth] "=&s"(soth), [tmp] "=&s"(tmp), [pop] "=&s"(pop)
+        : [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [best] "v"(best), [stk] "v"(stk_lds), [base] "s"(base),
+          [lds] "s"(lds_entries), [trav] "s"(trav), [inf] "v"(__builtin_inff())
+        : "vcc", "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
+          "s48", "s49", "s50", "s51");
+    return done;
+}
+
 #ifdef VMX_STEP_PROFILE
 // Diagnostic build only (tools/step_profile.py; make EXTRA=-DVMX_STEP_PROFILE): wave-cycles and wave-steps of
 // k_trace_w by the state in which the wave enters a step.  [SRC][category][0 = cycles, 1 = steps]; categories:
 // 0 every traversing lane at the same inner node, 1 inner nodes only (not all the same), 2 leaves only,
-// 3 inner nodes and leaves, 4 no traversing lane, 5 refill section, 6 steps of NaN-exact batches
+// 3 inner nodes and leaves, 4 no traversing lane, 5 refill section, 6 steps of NaN-exact batches and same-inner-node steps of waves whose rays do not share an octant,
+// 7 nodes done by uniform_descent
 __device__ unsigned long long g_step_prof[2][8][2];
 extern "C" int vmx_debug_step_profile(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_prof), sizeof(g_step_prof)) != hipSuccess) return -1;
@@ -1791,7 +1908,7 @@ extern "C" int vmx_debug_step_profile(unsigned long long *out, int reset) {
         const unsigned long long pl_ = __builtin_amdgcn_ballot_w64(cur != kIdle && (int)cur < 0);               \
         const uint32_t pc0_ = (uint32_t)__builtin_amdgcn_readlane((int)cur, pt_ ? (int)__ffsll((long long)pt_) - 1 : 0); \
         const bool pu_ = __builtin_amdgcn_ballot_w64(cur != kIdle && cur != pc0_) == 0;                         \
-        const uint32_t cat_ = decltype(EX)::value ? 6u : pt_ == 0 ? 4u : pl_ == pt_ ? 2u : pl_ != 0 ? 3u : pu_ ? 0u : 1u; \
+        const uint32_t cat_ = decltype(EX)::value ? 6u : pt_ == 0 ? 4u : pl_ == pt_ ? 2u : pl_ != 0 ? 3u : !pu_ ? 1u : decltype(OC)::value ? 0u : 6u; \
         const unsigned long long t0_ = __builtin_readcyclecounter();                                            \
         step(EX, OC);                                                                                           \
         const unsigned long long t1_ = __builtin_readcyclecounter();                                            \
@@ -1805,7 +1922,7 @@ extern "C" int vmx_debug_step_profile(unsigned long long *out, int reset) {
 #endif
 
 template <int SRC>
-__global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(VMX_TRACE_SGPRS)))
 k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     extern __shared__ uint2 lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -2122,7 +2239,30 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             uni_base = (const char *)inner + (size_t)wave_octant * wk.cam_n_inner * 64;
             // (16 steps per batch here: these waves refill only when all 64 lanes are done; measured 8 / 16 / 32)
 #pragma unroll 1
-            for (int act = 0; act < 16; ++act) VMX_PROF_STEP(std::false_type{}, std::true_type{});
+            for (int act = 0; act < 16; ++act) {
+                // all 64 lanes at the same inner node: the assembly loop takes the wave down the tree while that
+                // holds (uniform_descent), the general step goes on from where it stopped
+                const unsigned long long trav = __builtin_amdgcn_ballot_w64(cur != kIdle);
+                if (trav != 0) {
+                    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)__ffsll((long long)trav) - 1);
+                    if (c0 < kPop && __builtin_amdgcn_ballot_w64(cur != kIdle && (cur != c0 || sp >= lds_entries)) == 0)
+                    {
+#ifdef VMX_STEP_PROFILE
+                        const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+                        const uint32_t done = uniform_descent(sp, cur, ix, iy, iz, best, (uint32_t)(uintptr_t)stk, uni_base,
+                                                              c0, lds_entries, trav);
+                        act += (int)done;
+#ifdef VMX_STEP_PROFILE
+                        if (lane == 0) {
+                            s_prof[wave][7][0] += __builtin_readcyclecounter() - t0_;
+                            s_prof[wave][7][1] += done;
+                        }
+#endif
+                    }
+                }
+                VMX_PROF_STEP(std::false_type{}, std::true_type{});
+            }
         } else {
             uni_base = (const char *)inner;
 #pragma unroll 1
