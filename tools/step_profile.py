@@ -19,7 +19,7 @@ sc = va.Scene(pos, nrm, uv)
 out = torch.empty((H, W, 5), device="cuda")
 o = va.make_opts(seed=1, early_stop=False)
 sc.render_device(cam, o, out.data_ptr())
-buf = np.zeros((2, 8, 2), dtype=np.uint64)
+buf = np.zeros((2, 10, 2), dtype=np.uint64)
 fn(None, 1)
 sc.render_device(cam, o, out.data_ptr()); torch.cuda.synchronize()
 fn(buf.ctypes.data, 0)
@@ -29,6 +29,9 @@ names = ["same inner node", "inner nodes, not all the same", "leaves only", "inn
 for src, kn in enumerate(("k_trace_w<0> camera rays", "k_trace_w<1> bounce rays")):
     cyc, n = buf[src, :, 0].astype(float), buf[src, :, 1].astype(float)
     print(f"---- {kn}: {cyc.sum() / 1e9:.2f} G wave-cycles, {(n[:5].sum() + n[6] + n[7]) / 1e6:.1f} M wave-steps")
+    if n[8]:
+        print(f"uniform_descent: {n[8] / 1e6:.1f} M entries, {n[7] / n[8]:.2f} nodes per entry, {cyc[8] / n[8]:.1f} traversing lanes at entry")
+    cyc[8] = 0
     for i, nm in enumerate(names):
-        if n[i]:
+        if n[i] and i < 8:
             print(f"{nm:32s} {n[i] / 1e6:9.1f} M  {100 * n[i] / max(n[:5].sum() + n[6] + n[7], 1):5.1f} % of steps   {cyc[i] / n[i]:8.0f} cycles each   {100 * cyc[i] / cyc.sum():5.1f} % of wave-time")

@@ -1892,12 +1892,12 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
 // k_trace_w by the state in which the wave enters a step.  [SRC][category][0 = cycles, 1 = steps]; categories:
 // 0 every traversing lane at the same inner node, 1 inner nodes only (not all the same), 2 leaves only,
 // 3 inner nodes and leaves, 4 no traversing lane, 5 refill section, 6 steps of NaN-exact batches and same-inner-node steps of waves whose rays do not share an octant,
-// 7 nodes done by uniform_descent
-__device__ unsigned long long g_step_prof[2][8][2];
+// 7 nodes done by uniform_descent, 8 its entries (count; "cycles" = traversing lanes at entry, summed)
+__device__ unsigned long long g_step_prof[2][10][2];
 extern "C" int vmx_debug_step_profile(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_prof), sizeof(g_step_prof)) != hipSuccess) return -1;
     if (reset) {
-        static unsigned long long zero[2][8][2];
+        static unsigned long long zero[2][10][2];
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_step_prof), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;
@@ -1928,8 +1928,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const int lds_entries = (int)wk.lds_entries;
 #ifdef VMX_STEP_PROFILE
-    __shared__ unsigned long long s_prof[4][8][2];
-    if (lane < 16) s_prof[wave][lane >> 1][lane & 1] = 0;
+    __shared__ unsigned long long s_prof[4][10][2];
+    if (lane < 20) s_prof[wave][lane >> 1][lane & 1] = 0;
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
     uint2 *stk = lds_stack + (size_t)wave * (lds_entries + 1) * 64 + lane;
@@ -2257,6 +2257,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                         if (lane == 0) {
                             s_prof[wave][7][0] += __builtin_readcyclecounter() - t0_;
                             s_prof[wave][7][1] += done;
+                            s_prof[wave][8][1] += 1;  // entries
+                            s_prof[wave][8][0] += (unsigned long long)__popcll(trav);  // traversing lanes at entry
                         }
 #endif
                     }
@@ -2273,7 +2275,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
 #endif
     }
 #ifdef VMX_STEP_PROFILE
-    if (lane < 16) atomicAdd(&g_step_prof[SRC][lane >> 1][lane & 1], s_prof[wave][lane >> 1][lane & 1]);
+    if (lane < 20) atomicAdd(&g_step_prof[SRC][lane >> 1][lane & 1], s_prof[wave][lane >> 1][lane & 1]);
 #endif
 }
 
