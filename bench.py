@@ -211,6 +211,11 @@ def main():
                           "unit": "Gwave-inst/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
                           "traffic": d.get("hbm_bytes_per_launch"),
                           "valu_wave_insts_per_launch": int(d["valu_wave_insts_per_launch"]),
+                          # scalar ALU instructions share the issue slots (tools/sload_probe.hip): the same rate with them
+                          "salu_wave_insts_per_launch": int(d["salu_wave_insts_per_launch"]) if "salu_wave_insts_per_launch" in d else None,
+                          "issue_frac_valu_plus_salu": round((d["valu_wave_insts_per_launch"] + d["salu_wave_insts_per_launch"])
+                                                             / (avg_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
+                          if "salu_wave_insts_per_launch" in d else None,
                           "valu_lane_utilization": round(d.get("valu_lane_utilization", 0.0), 3),
                           "effective_clock_GHz_under_pmc": round(d.get("effective_clock_GHz", 0.0), 3),
                           "l1_accesses_per_clk_per_cu": round(d["l1_accesses_per_launch"] / (avg_ms * 1e-3) / 2.4e9 / 256, 3)

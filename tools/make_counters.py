@@ -62,6 +62,8 @@ def main():
             d["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8 / t / 1e9
         if "SQ_INSTS_VALU" in c:
             d["valu_wave_insts_per_launch"] = c["SQ_INSTS_VALU"]
+            if "SQ_INSTS_SALU" in c:  # scalar instructions take issue slots beside the vector ones (tools/sload_probe.hip)
+                d["salu_wave_insts_per_launch"] = c["SQ_INSTS_SALU"]
             # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles: peak = SIMDs x clock / 2
             d["valu_issue_frac_at_nominal_clock"] = c["SQ_INSTS_VALU"] / t / (N_SIMD * NOMINAL_HZ / 2)
             if "effective_clock_GHz" in d:

@@ -112,6 +112,20 @@ __global__ void __launch_bounds__(256, 8) k_probe(const float4 *__restrict__ tab
                 asm volatile("v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\t"
                              "v_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1\n\tv_mul_f32 %0, %0, %1"
                              : "+v"(acc) : "v"(ix));
+            } else if (MODE == 23) {  // 8 v_pk_mul_f32 (two products each)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 pa = {acc, a}, pb = {ix, iy};
+                asm volatile("v_pk_mul_f32 %0, %0, %1\n\tv_pk_mul_f32 %0, %0, %1\n\tv_pk_mul_f32 %0, %0, %1\n\tv_pk_mul_f32 %0, %0, %1\n\t"
+                             "v_pk_mul_f32 %0, %0, %1\n\tv_pk_mul_f32 %0, %0, %1\n\tv_pk_mul_f32 %0, %0, %1\n\tv_pk_mul_f32 %0, %0, %1"
+                             : "+v"(pa) : "v"(pb));
+                acc = pa.x + pa.y;
+            } else if (MODE == 24) {  // 8 independent v_pk_mul_f32
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 p0 = {acc, a}, p1 = {a, acc}, p2 = {t0, t1}, p3 = {t2, t3}, pb = {ix, iy};
+                asm volatile("v_pk_mul_f32 %0, %0, %4\n\tv_pk_mul_f32 %1, %1, %4\n\tv_pk_mul_f32 %2, %2, %4\n\tv_pk_mul_f32 %3, %3, %4\n\t"
+                             "v_pk_mul_f32 %0, %0, %4\n\tv_pk_mul_f32 %1, %1, %4\n\tv_pk_mul_f32 %2, %2, %4\n\tv_pk_mul_f32 %3, %3, %4"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));
+                acc = (p0.x + p1.y) + (p2.x + p3.y);
             } else if (MODE == 14) {  // 8 64-bit mask ops
                 unsigned long long m0 = idx, m1 = idx + 7;
                 asm volatile("s_and_b64 %0, %0, %1\n\ts_or_b64 %1, %0, %1\n\ts_and_b64 %0, %0, %1\n\ts_or_b64 %1, %0, %1\n\t"
@@ -211,6 +225,8 @@ int main() {
             run<12>("v12 v4 + s_cmp + 4 not-taken s_cbranch", tab, records, out, blocks);
             run<11>("v11 v4 + 8 v_cmp", tab, records, out, blocks);
             run<22>("v22 v4 + 8 v_mul", tab, records, out, blocks);
+            run<23>("v23 v4 + 8 dependent v_pk_mul_f32 (+1 add)", tab, records, out, blocks);
+            run<24>("v24 v4 + 8 independent v_pk_mul_f32 (+3 add)", tab, records, out, blocks);
             run<20>("v20 v4 + 8 x (v_mul, s_add) interleaved", tab, records, out, blocks);
             run<21>("v21 v4 + 8 v_mul then 8 s_add", tab, records, out, blocks);
             run<15>("v15 v4 + 1 ds_write_b64", tab, records, out, blocks);
