@@ -4,7 +4,7 @@
 One "step" = one full frame of the Sponza stand-in (256,152 triangles) at
 1920x1080, 256 spp, rendered by the HIP path tracer (PathTracer::Render
 equivalent), inputs resident in HBM before the timed region.  With N > 1 the
-frame is sharded into interleaved 16-row stripes (one process per GPU), the
+frame is sharded into interleaved 16-row (4-row beyond 4 ranks) stripes (one process per GPU), the
 packed stripes are gathered to rank 0 over RCCL and de-interleaved there; the
 gather and assembly are inside the timed step.
 
@@ -101,7 +101,9 @@ def main():
     c = camf()
     W, H, spp = args.width, args.height, args.spp
     cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
-    stripe = 16
+    # interleaved stripes: 16 rows up to 4 ranks, 4 rows beyond (measured per rank on one GPU, tools/shard_probe.py:
+    # the slowest of 8 ranks takes 17.5 ms with 16-row stripes, 16.7 ms with 4-row stripes; at 4 ranks 29.7 / 30.0 ms)
+    stripe = 16 if world <= 4 else 4
     rows = va.local_rows(H, stripe, rank, world)
     local = torch.empty((rows, W, 5), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream

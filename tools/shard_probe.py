@@ -9,8 +9,9 @@ W, H, spp = 1920, 1080, 256
 cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
 sc = va.Scene(pos, nrm, uv)
 out = torch.empty((H, W, 5), device="cuda")
+STRIPE = int(os.environ.get("STRIPE", "16"))
 def run(rank, world, **kw):
-    o = va.make_opts(seed=1, early_stop=False, rank=rank, world=world, stripe_rows=16, **kw)
+    o = va.make_opts(seed=1, early_stop=False, rank=rank, world=world, stripe_rows=STRIPE, **kw)
     sc.render_device(cam, o, out.data_ptr())
     t0 = time.perf_counter(); st = sc.render_device(cam, o, out.data_ptr()); torch.cuda.synchronize()
     return (time.perf_counter() - t0) * 1e3, st
