@@ -47,6 +47,7 @@ struct WorkDev {
     unsigned int *heads;        // [nsrc * 32] reservation heads, zeroed before the launch
     uint32_t nsrc;              // 8 image bands (primary) or kSubQueues (queue)
     uint32_t refill_min;        // refill when this many lanes of a wave are idle
+    uint32_t reserve;           // items a wave reserves per atomic on a head (multiple of 64)
     uint32_t shade_min;         // shade when this many lanes have finished traversal
     uint32_t leaf_min;          // k_paths: run the triangle step when this many lanes sit at a leaf
     uint32_t lds_entries;       // stack levels kept in LDS

@@ -34,6 +34,7 @@
 #define VMX_TRACE_WAVES_PER_SIMD 7  // register budget of the trace kernel: 512 / 7 -> 72 VGPRs
 #endif
 
+
 namespace vmx {
 namespace {
 
@@ -1209,7 +1210,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                  ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * wk.overflow_entries) * 64 + lane;
     const float4 *__restrict__ inner = (const float4 *)sc.inner;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    constexpr uint32_t kReserve = 256;
+    const uint32_t kReserve = wk.reserve;
 
     // wave-uniform scheduling state
     uint32_t src = blockIdx.x % wk.nsrc, res_lo = 0, res_hi = 0, tried = 0;
@@ -1534,7 +1535,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
     const float4 *__restrict__ tris = SRC == 0 ? (const float4 *)wk.cam_tris : (const float4 *)sc.tris;
     float2 *__restrict__ hit_out = (float2 *)pa.hit;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    constexpr uint32_t kReserve = 256;
+    const uint32_t kReserve = wk.reserve;
     constexpr int kActionsPerCheck = 8;  // traversal actions between two scheduling checks
     const uint32_t nsrc = wk.nsrc, refill_min = wk.refill_min;
     const uint32_t band_slots = wk.band_slots, band_items = wk.band_items;
@@ -1939,7 +1940,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     const float4 *__restrict__ tris = SRC == 0 ? (const float4 *)wk.cam_tris : (const float4 *)sc.tris;
     float2 *__restrict__ hit_out = (float2 *)pa.hit;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    constexpr uint32_t kReserve = 256;
+    const uint32_t kReserve = wk.reserve;
     constexpr uint32_t kIdle = 0x7FFFFFFFu, kBottom = 0x7FFFFFFEu, kPop = 0x7FFFFFFDu;  // never valid inner indices
     const uint32_t nsrc = wk.nsrc, refill_min = wk.refill_min;
     const uint32_t band_slots = wk.band_slots, band_items = wk.band_items;
