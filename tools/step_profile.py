@@ -20,9 +20,16 @@ out = torch.empty((H, W, 5), device="cuda")
 o = va.make_opts(seed=1, early_stop=False)
 sc.render_device(cam, o, out.data_ptr())
 buf = np.zeros((2, 10, 2), dtype=np.uint64)
-fn(None, 1)
+ws = lib.vmx_debug_wave_span
+ws.argtypes = [ctypes.c_void_p, ctypes.c_int]
+span = np.zeros((2, 4), dtype=np.uint64)
+fn(None, 1); ws(None, 1)
 sc.render_device(cam, o, out.data_ptr()); torch.cuda.synchronize()
-fn(buf.ctypes.data, 0)
+fn(buf.ctypes.data, 0); ws(span.ctypes.data, 0)
+for src, kn in enumerate(("k_trace_w<0>", "k_trace_w<1>")):
+    if span[src, 3]:
+        first, last, tot, n = (float(x) for x in span[src])
+        print(f"{kn}: {int(n)} waves (all launches of the frame), last wave ends {(last - first) / 100:.0f} us after the first one starts, the average wave {(tot / n - first) / 100:.0f} us")
 print({k: round(v["ms"], 2) for k, v in sc.timings().items() if v["launches"]})
 names = ["same inner node", "inner nodes, not all the same", "leaves only", "inner nodes and leaves", "no traversing lane",
          "refill section", "NaN-exact batch / same node, mixed octants", "uniform_descent (asm loop)"]

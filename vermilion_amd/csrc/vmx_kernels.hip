@@ -1895,6 +1895,16 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
 // 3 inner nodes and leaves, 4 no traversing lane, 5 refill section, 6 steps of NaN-exact batches and same-inner-node steps of waves whose rays do not share an octant,
 // 7 nodes done by uniform_descent, 8 its entries (count; "cycles" = traversing lanes at entry, summed)
 __device__ unsigned long long g_step_prof[2][10][2];
+// per launch kind: [0] earliest wave start, [1] latest wave end, [2] sum of wave ends, [3] waves (100 MHz wall clock)
+__device__ unsigned long long g_wave_span[2][4];
+extern "C" int vmx_debug_wave_span(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_span), sizeof(g_wave_span)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long init[2][4] = {{~0ull, 0, 0, 0}, {~0ull, 0, 0, 0}};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_span), init, sizeof(init)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 extern "C" int vmx_debug_step_profile(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_prof), sizeof(g_step_prof)) != hipSuccess) return -1;
     if (reset) {
@@ -1932,6 +1942,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     __shared__ unsigned long long s_prof[4][10][2];
     if (lane < 20) s_prof[wave][lane >> 1][lane & 1] = 0;
     unsigned long long prof_t = __builtin_readcyclecounter();
+    if (lane == 0) atomicMin(&g_wave_span[SRC][0], (unsigned long long)wall_clock64());
 #endif
     uint2 *stk = lds_stack + (size_t)wave * (lds_entries + 1) * 64 + lane;
     uint2 *ovf = (uint2 *)wk.overflow_stack +
@@ -2277,6 +2288,12 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     }
 #ifdef VMX_STEP_PROFILE
     if (lane < 20) atomicAdd(&g_step_prof[SRC][lane >> 1][lane & 1], s_prof[wave][lane >> 1][lane & 1]);
+    if (lane == 0) {
+        const unsigned long long now = (unsigned long long)wall_clock64();
+        atomicMax(&g_wave_span[SRC][1], now);
+        atomicAdd(&g_wave_span[SRC][2], now);
+        atomicAdd(&g_wave_span[SRC][3], 1ull);
+    }
 #endif
 }
 
