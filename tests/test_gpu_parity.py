@@ -564,3 +564,64 @@ def test_lbvh_scene_creation_is_a_per_frame_operation_f1():
         leaves = tree["right_offset"] == 0
         assert tree["nprims"][leaves].sum() == n and tree["nprims"][leaves].max() <= leaf
         g.close()
+
+
+def _random_soup(rng, n, kind):
+    """triangle soups that stress the tree and the traversal: flat axis-aligned sheets (zero-thickness boxes),
+    duplicated triangles (exact distance ties), slivers and degenerate (zero-area) triangles, huge + tiny mixed"""
+    if kind == "sheets":  # triangles lying in a few axis-aligned planes, shared edges
+        ax = rng.integers(0, 3, n)
+        plane = rng.choice(np.float32([-300, 0, 250, 600]), n)
+        c = rng.uniform(-800, 800, (n, 1, 3)).astype(np.float32)
+        p = c + rng.uniform(-120, 120, (n, 3, 3)).astype(np.float32)
+        p[np.arange(n), :, ax] = plane[:, None]
+    elif kind == "duplicates":
+        m = max(n // 3, 1)
+        base = (rng.uniform(-600, 600, (m, 1, 3)) + rng.uniform(-90, 90, (m, 3, 3))).astype(np.float32)
+        p = base[rng.integers(0, m, n)]  # every triangle several times: ties are resolved by test order
+    elif kind == "slivers":
+        c = rng.uniform(-700, 700, (n, 1, 3)).astype(np.float32)
+        p = c + rng.uniform(-200, 200, (n, 3, 3)).astype(np.float32)
+        k = rng.random(n) < 0.3
+        p[k, 2] = p[k, 0] + (p[k, 1] - p[k, 0]) * rng.uniform(0, 1, (int(k.sum()), 1)).astype(np.float32)  # collinear
+        z = rng.random(n) < 0.05
+        p[z, 1] = p[z, 0]  # two equal vertices
+    else:  # "scales": a few huge triangles over many tiny ones
+        c = rng.uniform(-500, 500, (n, 1, 3)).astype(np.float32)
+        s = np.where(rng.random((n, 1, 1)) < 0.03, 2500.0, 12.0).astype(np.float32)
+        p = c + rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32) * s
+    p = np.ascontiguousarray(p, np.float32)
+    nr = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]).astype(np.float32)
+    ln = np.linalg.norm(nr, axis=1, keepdims=True)
+    nr = np.where(ln > 0, nr / np.maximum(ln, 1e-30), np.float32([0, 1, 0])).astype(np.float32)
+    return p, np.repeat(nr[:, None, :], 3, axis=1).copy(), None
+
+
+@pytest.mark.parametrize("kind", ["sheets", "duplicates", "slivers", "scales"])
+def test_random_soups_production_kernels_bit_exact(kind):
+    """random scenes no modeller would produce, through the kernels the bench frame runs (split pipeline:
+    k_trace_w<0> with its assembly descent loop, k_trace_w<1>, k_shade, tail) and the default form: triangle IDs,
+    distances and whole frames against the oracle, at several LDS stack depths"""
+    rng = np.random.default_rng({"sheets": 11, "duplicates": 12, "slivers": 13, "scales": 14}[kind])
+    for n, leaf in ((1, 4), (37, 1), (700, 4), (5000, 2), (20000, 7)):
+        pos, nrm, uv = _random_soup(rng, n, kind)
+        p = Pair(pos, nrm, uv, leaf_size=leaf)
+        g, c = p.gpu.bvh(), p.cpu.bvh()
+        for k in g:
+            assert np.array_equal(g[k], c[k]), (kind, n, k)
+        o, d = rand_rays(30000, n + leaf, lo=(-900, -900, -900), hi=(900, 900, 900))
+        tri, t = p.gpu.trace(o, d)
+        rtri, rt = p.cpu.trace(o, d)
+        assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt)), (kind, n)
+        cam = va.make_camera((40.0, 300.0, 1900.0), (0.0, 0.0, 0.0), 72, 40, 64)
+        ref, rst = p.cpu.render(cam, va.make_opts(seed=5, early_stop=False))
+        for kw in ({}, {"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1, "lds_entries": 2},
+                   {"pipeline": 4, "lds_entries": 40}):
+            img, st = p.gpu.render(cam, va.make_opts(seed=5, early_stop=False, **kw))
+            assert np.array_equal(bits(img), bits(ref)), (kind, n, kw)
+            assert st["rays_secondary"] == rst["rays_secondary"]
+        ids, tt = p.gpu.primary_ids(cam, va.make_opts(seed=5), 3)
+        oo, dd = O.primary_rays(cam, va.make_opts(seed=5), 3)
+        rids, rtt = p.cpu.trace(oo, dd)
+        assert np.array_equal(ids, rids) and np.array_equal(bits(tt), bits(rtt)), (kind, n)
+        p.close()
