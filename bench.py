@@ -161,6 +161,30 @@ def main():
     # §8 f-1 quality builder (binned SAH, not the reference's topology): same frame, extra figure only
     q_info = None
     if world == 1 and not args.no_extras:
+        # ... and the same quality from the GPU builder (PLOC): scene creation is then a per-frame operation
+        va.Scene(pos, nrm, uv, device=dev_index, builder=va._lib.VMX_BVH_PLOC).close()  # first hipcub launches
+        t0 = time.perf_counter()
+        psc = va.Scene(pos, nrm, uv, device=dev_index, builder=va._lib.VMX_BVH_PLOC)
+        p_build = time.perf_counter() - t0
+        popts = va.make_opts(seed=args.seed, early_stop=False, collect_counters=True)
+        pc = psc.render_device(cam, popts, local.data_ptr(), stream)
+        popts = va.make_opts(seed=args.seed, early_stop=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pk = max(1, min(args.steps, 3))
+        pst = [psc.render_device(cam, popts, local.data_ptr(), stream) for _ in range(pk)]
+        torch.cuda.synchronize(dev)
+        pdt = time.perf_counter() - t0
+        p_info = {
+            "what": "same frame over the tree the GPU builds by parallel locally-ordered clustering (VMX_BVH_PLOC); "
+                    "scene_create_ms includes the host-to-device copy of the triangles",
+            "scene_create_ms": round(p_build * 1e3, 2),
+            "Mrays_per_s": round(sum(s["rays_primary"] + s["rays_secondary"] for s in pst) / pdt / 1e6, 2),
+            "ms_per_frame": round(pdt / pk * 1e3, 3),
+            "inner_visits_per_ray": round(pc["primary"]["inner_visits"] / max(pc["primary"]["rays"], 1), 2),
+            "bvh": {k: psc.describe()[k] for k in ("n_nodes", "max_depth")},
+        }
+        psc.close()
         qsc = va.Scene(pos, nrm, uv, device=dev_index, builder=va._lib.VMX_BVH_SAH)
         qopts = va.make_opts(seed=args.seed, early_stop=False, collect_counters=True)
         qc = qsc.render_device(cam, qopts, local.data_ptr(), stream)
@@ -292,6 +316,7 @@ def main():
             }
         if q_info:
             out["quality_bvh"] = q_info
+            out["quality_bvh_gpu_built"] = p_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, nrm, uv, c, W, H, args.cpu_spp, args.seed)
         print(json.dumps(out), flush=True)

@@ -201,6 +201,9 @@ int vmx_scene_create(const float *pos, const float *nrm, const float *uv, uint32
                                 for scenes that change per frame; same caveat as SAH.  Many coincident
                                 centroids can make the tree deeper than the 64-entry traversal stack the
                                 reference allows (bvh.cpp:54): VMX_ERR_DEPTH, use another builder */
+#define VMX_BVH_PLOC 3u      /* quality tree built on the GPU by parallel locally-ordered clustering (Morton
+                                sort, rounds of nearest-neighbour merging within 16 positions): close to the SAH
+                                tree's visit counts at a few ms per build; same caveat as SAH */
 int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uint32_t ntris,
                         const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size, uint32_t builder,
                         int device, vmx_scene **out);

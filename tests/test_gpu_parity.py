@@ -495,15 +495,16 @@ def test_textured_paths_bit_exact_f2(channels, size):
 
 
 @pytest.mark.parametrize("name", ["lattice", "bunny70k", "sponza260k"])
-@pytest.mark.parametrize("builder", ["sah", "lbvh"])
+@pytest.mark.parametrize("builder", ["sah", "lbvh", "ploc"])
 def test_quality_bvh_builder_f1(name, builder):
-    """§8 f-1: the binned-SAH tree (host) and the linear BVH built on the GPU.  (1) the reference's traversal run over the SAME tree (oracle fed
+    """§8 f-1: the binned-SAH tree (host), the linear BVH and the PLOC quality tree built on the GPU.  (1) the reference's traversal run over the SAME tree (oracle fed
     the exported flat tree) agrees bit for bit; (2) against the reference-topology tree the nearest hit
     is the same triangle at the same distance except where two triangles are hit at the same t."""
     gen, camf = scenes.SCENES[name]
     pos, nrm, uv = gen()
     ref = va.Scene(pos, nrm, uv)
-    sah = va.Scene(pos, nrm, uv, builder=va._lib.VMX_BVH_SAH if builder == "sah" else va._lib.VMX_BVH_LBVH)
+    sah = va.Scene(pos, nrm, uv, builder={"sah": va._lib.VMX_BVH_SAH, "lbvh": va._lib.VMX_BVH_LBVH,
+                                          "ploc": va._lib.VMX_BVH_PLOC}[builder])
     tree = sah.bvh()
     d = sah.describe()
     assert d["n_nodes"] == len(tree["start"]) and sorted(tree["prim_order"].tolist()) == list(range(pos.shape[0]))
@@ -529,8 +530,8 @@ def test_quality_bvh_builder_f1(name, builder):
         img, st = sah.render(cam, opts)
         oimg, ost = osc.render(cam, opts)
         assert np.array_equal(bits(img), bits(oimg))
-    if name == "sponza260k" and builder == "sah":
-        # the point of the builder: fewer node visits than the reference's median split
+    if name == "sponza260k" and builder in ("sah", "ploc"):
+        # the point of these builders: fewer node visits than the reference's median split
         _, _, rcnt = O.OracleScene(pos, nrm, uv).trace(o, dd, counters=True)
         assert cnt["inner_visits"] < 0.7 * rcnt["inner_visits"]
     ref.close()
@@ -552,15 +553,16 @@ def test_lbvh_scene_creation_is_a_per_frame_operation_f1():
         sc.close()
     assert best < 0.015, f"LBVH scene creation took {best * 1e3:.1f} ms"
     # leaf sizes and tiny inputs through the device emission
-    for n, leaf in ((1, 4), (2, 4), (5, 1), (7, 31), (200, 3)):
+    for n, leaf, bld in [(n, leaf, b) for (n, leaf) in ((1, 4), (2, 4), (5, 1), (7, 31), (200, 3), (3, 2))
+                         for b in (va._lib.VMX_BVH_LBVH, va._lib.VMX_BVH_PLOC)]:
         p2, n2, u2 = (scenes.lattice() if n > 8 else scenes.cornell8())
-        g = va.Scene(p2[:n], n2[:n], u2[:n], leaf_size=leaf, builder=va._lib.VMX_BVH_LBVH)
+        g = va.Scene(p2[:n], n2[:n], u2[:n], leaf_size=leaf, builder=bld)
         tree = g.bvh()
         osc = O.OracleScene(p2[:n], n2[:n], u2[:n], tree=tree)
         o, d = rand_rays(20000, n + leaf, lo=(-900, 5, -700), hi=(900, 900, 1500))
         tri, t = g.trace(o, d)
         otri, ot = osc.trace(o, d)
-        assert np.array_equal(tri, otri) and np.array_equal(bits(t), bits(ot)), (n, leaf)
+        assert np.array_equal(tri, otri) and np.array_equal(bits(t), bits(ot)), (n, leaf, bld)
         leaves = tree["right_offset"] == 0
         assert tree["nprims"][leaves].sum() == n and tree["nprims"][leaves].max() <= leaf
         g.close()

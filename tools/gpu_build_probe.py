@@ -1,4 +1,4 @@
-"""Scene build time and frame time per BVH builder (0 reference topology, 1 binned SAH on the host, 2 LBVH on the GPU)."""
+"""Scene build time and frame time per BVH builder (0 reference topology, 1 binned SAH on the host, 2 LBVH on the GPU, 3 PLOC on the GPU)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +14,7 @@ W, H, spp = 1920, 1080, 64
 cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
 out = torch.empty((H, W, 5), dtype=torch.float32, device="cuda")
 va.Scene(pos, nrm, uv).close()  # warm the context
-for b, label in ((0, "reference"), (1, "SAH host"), (2, "LBVH gpu")):
+for b, label in ((0, "reference"), (1, "SAH host"), (2, "LBVH gpu"), (3, "PLOC gpu")):
     ts = []
     for r in range(3):
         t0 = time.time()

@@ -23,6 +23,7 @@ VMX_SAMPLING_CORRECTED = 1
 VMX_BVH_REFERENCE = 0
 VMX_BVH_SAH = 1
 VMX_BVH_LBVH = 2
+VMX_BVH_PLOC = 3
 VMX_BF_ABS_INT = 1
 
 

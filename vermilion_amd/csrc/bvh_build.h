@@ -51,6 +51,9 @@ struct LbvhDevice {
 };
 bool build_bvh_lbvh_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
                            int device, LbvhDevice &out, std::string &err);
+// the same product from parallel locally-ordered clustering (PLOC): a quality tree, also built entirely on the GPU
+bool build_bvh_ploc_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
+                           int device, LbvhDevice &out, std::string &err);
 // reference flat layout (start / nprims / right_offset / bbox / prim_order, n_leaves, max_depth) of such a tree
 bool lbvh_export_flat(const LbvhDevice &d, int device, HostBvh &out, std::string &err);
 void lbvh_release(LbvhDevice &d);

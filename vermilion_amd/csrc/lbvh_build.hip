@@ -1,4 +1,5 @@
-// lbvh_build.hip — BVH construction on the GPU: a linear BVH.
+// lbvh_build.hip — BVH construction on the GPU: a linear BVH, and a quality tree by parallel
+// locally-ordered clustering (k_ploc_*, below) that shares its Morton sort, record emission and flat export.
 //
 //   k_lbvh_bounds     centroid bounds (wave min/max + integer atomics on order-preserving float keys)
 //   k_lbvh_keys       63-bit Morton code of each triangle's centroid (21 bits per axis, over the
@@ -32,6 +33,11 @@
 
 namespace vmx {
 namespace {
+
+#ifndef VMX_PLOC_RADIUS
+#define VMX_PLOC_RADIUS 16
+#endif
+constexpr int kPlocRadius = VMX_PLOC_RADIUS;  // neighbours searched on each side (PLOC)
 
 #define LB_TRY(expr)                                                            \
     do {                                                                        \
@@ -255,6 +261,146 @@ __global__ void k_lbvh_keys(const float *__restrict__ pos, uint32_t n, const int
     ids[i] = i;
 }
 
+
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) -----------------------------------
+// A quality tree built bottom-up on the GPU: the clusters (at first the triangles in Morton order) each look
+// for the neighbour within `radius` positions whose union box has the smallest surface area; pairs that chose
+// each other merge into a new node, the cluster array is compacted, and the rounds repeat until one cluster
+// is left.  Everything that orders the result is a scan or a strict total order on pairs (area, lower
+// position, higher position), so the tree is the same on every run.  Node indices are handed out from the top
+// (the last merge gets index 0): the emission kernels take inner record 0 as the root, as for the Karras tree.
+__device__ __forceinline__ float ploc_half_area(const float *a, const float *b) {
+    const float dx = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), dy = fmaxf(a[4], b[4]) - fminf(a[1], b[1]),
+                dz = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void k_ploc_leaf_boxes(const float *__restrict__ pos, const uint32_t *__restrict__ ids_m, int n,
+                                  float *__restrict__ box_m, uint32_t *__restrict__ c_node, float *__restrict__ c_box) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pos + (size_t)ids_m[i] * 9;
+    for (int a = 0; a < 3; ++a) {
+        const float lo = fminf(fminf(p[a], p[3 + a]), p[6 + a]), hi = fmaxf(fmaxf(p[a], p[3 + a]), p[6 + a]);
+        box_m[(size_t)i * 6 + a] = lo, box_m[(size_t)i * 6 + 3 + a] = hi;
+        c_box[(size_t)i * 6 + a] = lo, c_box[(size_t)i * 6 + 3 + a] = hi;
+    }
+    c_node[i] = 0x80000000u | (uint32_t)i;
+}
+
+__global__ void k_ploc_nearest(int nc, int radius, const float *__restrict__ c_box, uint32_t *__restrict__ nn) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    float mine[6];
+    for (int a = 0; a < 6; ++a) mine[a] = c_box[(size_t)i * 6 + a];
+    float best = INFINITY;
+    int bj = -1;
+    const int lo = max(i - radius, 0), hi = min(i + radius, nc - 1);
+    for (int j = lo; j <= hi; ++j) {
+        if (j == i) continue;
+        const float a = ploc_half_area(mine, c_box + (size_t)j * 6);
+        // strict total order on pairs: (area, lower position, higher position)
+        bool better = bj < 0 || a < best;
+        if (!better && a == best) {
+            const int m0 = min(i, j), m1 = max(i, j), b0 = min(i, bj), b1 = max(i, bj);
+            better = m0 < b0 || (m0 == b0 && m1 < b1);
+        }
+        if (better) best = a, bj = j;
+    }
+    nn[i] = (uint32_t)bj;
+}
+
+// survivor (bit 0) and merge-leader (bit 32) flags of cluster i
+__global__ void k_ploc_flags(int nc, const uint32_t *__restrict__ nn, unsigned long long *__restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    const uint32_t j = nn[i];
+    const bool mutual = nn[j] == (uint32_t)i;
+    const bool leader = mutual && (uint32_t)i < j;
+    const bool absorbed = mutual && (uint32_t)i > j;
+    flags[i] = (absorbed ? 0ull : 1ull) | (leader ? (1ull << 32) : 0ull);
+}
+
+__global__ void k_ploc_commit(int nc, uint32_t base, const uint32_t *__restrict__ nn,
+                              const unsigned long long *__restrict__ flags, const unsigned long long *__restrict__ scan,
+                              const uint32_t *__restrict__ c_node, const float *__restrict__ c_box,
+                              uint32_t *__restrict__ n_node, float *__restrict__ n_box, uint32_t *__restrict__ left,
+                              uint32_t *__restrict__ right, uint32_t *__restrict__ parent_of_internal,
+                              uint32_t *__restrict__ parent_of_leaf, float *__restrict__ node_box,
+                              uint32_t *__restrict__ height, uint32_t *__restrict__ size) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    const unsigned long long f = flags[i];
+    if (!(f & 1ull)) return;  // absorbed by its partner
+    const uint32_t pos = (uint32_t)scan[i];
+    if (!(f >> 32)) {
+        n_node[pos] = c_node[i];
+        for (int a = 0; a < 6; ++a) n_box[(size_t)pos * 6 + a] = c_box[(size_t)i * 6 + a];
+        return;
+    }
+    const uint32_t j = nn[i], idx = base - 1u - (uint32_t)(scan[i] >> 32);
+    const uint32_t lc = c_node[i], rc = c_node[j];
+    left[idx] = lc, right[idx] = rc;
+    float b[6];
+    for (int a = 0; a < 3; ++a) {
+        b[a] = fminf(c_box[(size_t)i * 6 + a], c_box[(size_t)j * 6 + a]);
+        b[3 + a] = fmaxf(c_box[(size_t)i * 6 + 3 + a], c_box[(size_t)j * 6 + 3 + a]);
+    }
+    for (int a = 0; a < 6; ++a) node_box[(size_t)idx * 6 + a] = b[a], n_box[(size_t)pos * 6 + a] = b[a];
+    const uint32_t lh = (lc & 0x80000000u) ? 0u : height[lc], rh = (rc & 0x80000000u) ? 0u : height[rc];
+    const uint32_t ls = (lc & 0x80000000u) ? 1u : size[lc], rs = (rc & 0x80000000u) ? 1u : size[rc];
+    height[idx] = max(lh, rh) + 1u, size[idx] = ls + rs;
+    if (lc & 0x80000000u) parent_of_leaf[lc & 0x7FFFFFFFu] = idx;
+    else parent_of_internal[lc] = idx;
+    if (rc & 0x80000000u) parent_of_leaf[rc & 0x7FFFFFFFu] = idx;
+    else parent_of_internal[rc] = idx;
+    parent_of_internal[idx] = 0xFFFFFFFFu;  // until a later round gives it a parent
+    n_node[pos] = idx;
+}
+
+// depth-first position of every triangle (and first / last of every node): the triangles of a subtree must be
+// contiguous in leaf order, and merging clusters that are not neighbours breaks the Morton order's contiguity.
+// A node's first position = the triangles to the left of it = the sizes of the left siblings on its way up.
+__device__ __forceinline__ uint32_t ploc_first(uint32_t self, uint32_t node, const uint32_t *left, const uint32_t *right,
+                                               const uint32_t *parent_of_internal, const uint32_t *size) {
+    uint32_t pos = 0;
+    while (node != 0xFFFFFFFFu) {
+        if (right[node] == self) {
+            const uint32_t l = left[node];
+            pos += (l & 0x80000000u) ? 1u : size[l];
+        }
+        self = node;
+        node = parent_of_internal[node];
+    }
+    return pos;
+}
+__global__ void k_ploc_order(int n, const uint32_t *__restrict__ ids_m, const float *__restrict__ box_m,
+                             const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                             const uint32_t *__restrict__ parent_of_internal, const uint32_t *__restrict__ parent_of_leaf,
+                             const uint32_t *__restrict__ size, uint32_t *__restrict__ dfs_of_slot, uint32_t *__restrict__ ids,
+                             float *__restrict__ leaf_box, uint32_t *__restrict__ first, uint32_t *__restrict__ last) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t pos = n > 1 ? ploc_first(0x80000000u | (uint32_t)i, parent_of_leaf[i], left, right, parent_of_internal, size) : 0u;
+        dfs_of_slot[i] = pos;
+        ids[pos] = ids_m[i];
+        for (int a = 0; a < 6; ++a) leaf_box[(size_t)pos * 6 + a] = box_m[(size_t)i * 6 + a];
+    }
+    if (i < n - 1) {
+        const uint32_t f = ploc_first((uint32_t)i, parent_of_internal[i], left, right, parent_of_internal, size);
+        first[i] = f, last[i] = f + size[i] - 1u;
+    }
+}
+// child references to triangles: Morton slot -> depth-first position
+__global__ void k_ploc_relink(int n, const uint32_t *__restrict__ dfs_of_slot, uint32_t *__restrict__ left,
+                              uint32_t *__restrict__ right) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const uint32_t l = left[i], r = right[i];
+    if (l & 0x80000000u) left[i] = 0x80000000u | dfs_of_slot[l & 0x7FFFFFFFu];
+    if (r & 0x80000000u) right[i] = 0x80000000u | dfs_of_slot[r & 0x7FFFFFFFu];
+}
+
 template <class T>
 T *carve(unsigned char *&cursor, size_t count) {
     T *p = (T *)cursor;
@@ -274,8 +420,8 @@ void lbvh_release(LbvhDevice &d) {
 // The whole build on the device: upload -> Morton keys -> radix sort -> Karras hierarchy -> bottom-up fit ->
 // InnerRecord / TriRecord / AttrRecord emission.  Nothing comes back to the host except the root's height
 // (for the traversal stack depth); the hierarchy arrays stay in `out.arena` for lbvh_export_flat.
-bool build_bvh_lbvh_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
-                           int device, LbvhDevice &out, std::string &err) {
+static bool build_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
+                         int device, bool ploc, LbvhDevice &out, std::string &err) {
     if (!check_bvh_input(pos, nrm, ntris, leaf_size, err)) return false;
     const int n = (int)ntris;
     const size_t ni = n > 1 ? (size_t)n - 1 : 1;
@@ -292,6 +438,13 @@ bool build_bvh_lbvh_device(const float *pos, const float *nrm, const float *uv, 
     add(in_floats * 4), add((size_t)n * 8), add((size_t)n * 8), add((size_t)n * 4), add((size_t)n * 4);  // inputs, keys x2, ids x2
     for (int k = 0; k < 6; ++k) add(ni * 4);                                                             // left right first last pint height
     add((size_t)n * 4), add(ni * 4), add((size_t)n * 24), add(ni * 24), add(256), add(tmp_bytes);        // pleaf arrivals leaf_box node_box bounds tmp
+    size_t scan_bytes = 0;
+    if (ploc) {
+        LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, n));
+        add((size_t)n * 24), add((size_t)n * 4), add((size_t)n * 4);                        // box_m, cluster nodes x2
+        add((size_t)n * 24), add((size_t)n * 24), add((size_t)n * 4), add((size_t)n * 4);   // cluster boxes x2, nn, dfs_of_slot
+        add((size_t)n * 8), add((size_t)n * 8), add(ni * 4), add(scan_bytes);               // flags, scan, size, scan temp
+    }
     LB_TRY(hipMalloc(&out.arena, arena_bytes));
     out.arena_bytes = arena_bytes;
     unsigned char *cur = (unsigned char *)out.arena;
@@ -333,13 +486,54 @@ bool build_bvh_lbvh_device(const float *pos, const float *nrm, const float *uv, 
     hipLaunchKernelGGL(k_lbvh_keys, grd, blk, 0, s, d_pos, ntris, d_bounds, d_keys, d_ids);
     LB_TRY(hipGetLastError());
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_ids, out.ids, n, 0, 63, s));
-    if (n > 1) {
-        hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n - 1 + 255) / 256), blk, 0, s, d_keys2, n, out.left, out.right,
-                           out.first, out.last, d_pint, d_pleaf);
+    if (ploc) {
+        float *box_m = carve<float>(cur, (size_t)n * 6);
+        uint32_t *c_node[2] = {carve<uint32_t>(cur, n), carve<uint32_t>(cur, n)};
+        float *c_box[2] = {carve<float>(cur, (size_t)n * 6), carve<float>(cur, (size_t)n * 6)};
+        uint32_t *d_nn = carve<uint32_t>(cur, n), *d_dfs = carve<uint32_t>(cur, n);
+        unsigned long long *d_flags = carve<unsigned long long>(cur, n), *d_scan = carve<unsigned long long>(cur, n);
+        uint32_t *d_size = carve<uint32_t>(cur, ni);
+        unsigned char *d_scan_tmp = carve<unsigned char>(cur, scan_bytes);
+        // out.ids holds the Morton order until k_ploc_order rewrites it in depth-first order: keep a copy in d_ids
+        LB_TRY(hipMemcpyAsync(d_ids, out.ids, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_ploc_leaf_boxes, grd, blk, 0, s, d_pos, d_ids, n, box_m, c_node[0], c_box[0]);
         LB_TRY(hipGetLastError());
+        int nc = n, from = 0;
+        uint32_t base = (uint32_t)(n - 1);
+        while (nc > 1) {
+            const dim3 g((nc + 255) / 256);
+            hipLaunchKernelGGL(k_ploc_nearest, g, blk, 0, s, nc, kPlocRadius, c_box[from], d_nn);
+            hipLaunchKernelGGL(k_ploc_flags, g, blk, 0, s, nc, d_nn, d_flags);
+            LB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_tmp, scan_bytes, d_flags, d_scan, nc, s));
+            hipLaunchKernelGGL(k_ploc_commit, g, blk, 0, s, nc, base, d_nn, d_flags, d_scan, c_node[from], c_box[from],
+                               c_node[from ^ 1], c_box[from ^ 1], out.left, out.right, d_pint, d_pleaf, out.node_box,
+                               d_height, d_size);
+            LB_TRY(hipGetLastError());
+            unsigned long long tail[2];  // totals = last scan value + last flag
+            LB_TRY(hipMemcpyAsync(&tail[0], d_scan + (nc - 1), 8, hipMemcpyDeviceToHost, s));
+            LB_TRY(hipMemcpyAsync(&tail[1], d_flags + (nc - 1), 8, hipMemcpyDeviceToHost, s));
+            LB_TRY(hipStreamSynchronize(s));
+            const unsigned long long tot = tail[0] + tail[1];
+            const uint32_t merged = (uint32_t)(tot >> 32);
+            if (merged == 0) {
+                err = "PLOC builder: a round merged nothing";
+                return false;
+            }
+            nc = (int)(uint32_t)tot, base -= merged, from ^= 1;
+        }
+        hipLaunchKernelGGL(k_ploc_order, grd, blk, 0, s, n, d_ids, box_m, out.left, out.right, d_pint, d_pleaf, d_size,
+                           d_dfs, out.ids, out.leaf_box, out.first, out.last);
+        if (n > 1) hipLaunchKernelGGL(k_ploc_relink, dim3((n - 1 + 255) / 256), blk, 0, s, n, d_dfs, out.left, out.right);
+        LB_TRY(hipGetLastError());
+    } else {
+        if (n > 1) {
+            hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n - 1 + 255) / 256), blk, 0, s, d_keys2, n, out.left, out.right,
+                               out.first, out.last, d_pint, d_pleaf);
+            LB_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, s, d_pos, out.ids, n, out.left, out.right, d_pint, d_pleaf, out.leaf_box,
+                           out.node_box, d_height, d_arr);
     }
-    hipLaunchKernelGGL(k_lbvh_fit, grd, blk, 0, s, d_pos, out.ids, n, out.left, out.right, d_pint, d_pleaf, out.leaf_box,
-                       out.node_box, d_height, d_arr);
     if (n > 1)
         hipLaunchKernelGGL(k_lbvh_emit_inner, dim3((n - 1 + 255) / 256), blk, 0, s, n, leaf_size, out.left, out.right,
                            out.first, out.last, out.leaf_box, out.node_box, (InnerRecord *)out.geom);
@@ -358,6 +552,15 @@ bool build_bvh_lbvh_device(const float *pos, const float *nrm, const float *uv, 
     }
     out.root_ref = ntris <= leaf_size ? (kLeafBit | (ntris << kLeafCountShift)) : 0u;
     return true;
+}
+
+bool build_bvh_lbvh_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
+                           int device, LbvhDevice &out, std::string &err) {
+    return build_device(pos, nrm, uv, ntris, leaf_size, device, false, out, err);
+}
+bool build_bvh_ploc_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
+                           int device, LbvhDevice &out, std::string &err) {
+    return build_device(pos, nrm, uv, ntris, leaf_size, device, true, out, err);
 }
 
 // The reference's flat layout (bvh.h:11-14) of a device-built tree, for vmx_scene_bvh / vmx_scene_describe:

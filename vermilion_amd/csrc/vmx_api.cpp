@@ -858,7 +858,7 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
                         const vmx_sphere *spheres, uint32_t nspheres, uint32_t leaf_size, uint32_t builder,
                         int device, vmx_scene **out) {
     if (!out) return fail(VMX_ERR_INVALID, "out is NULL");
-    if (builder > VMX_BVH_LBVH) return fail(VMX_ERR_INVALID, "unknown BVH builder");
+    if (builder > VMX_BVH_PLOC) return fail(VMX_ERR_INVALID, "unknown BVH builder");
     *out = nullptr;
     if (!pos || !nrm || ntris == 0) return fail(VMX_ERR_INVALID, "scene needs positions, normals, ntris > 0");
     if (spheres == nullptr && nspheres != 0)
@@ -875,9 +875,10 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
     sc->leaf_size = leaf_size ? leaf_size : 4;
     std::string err;
     bool built;
-    if (builder == VMX_BVH_LBVH) {
+    if (builder == VMX_BVH_LBVH || builder == VMX_BVH_PLOC) {
         sc->device_built = true, sc->flat_ready = false;
-        built = build_bvh_lbvh_device(pos, nrm, uv, ntris, sc->leaf_size, device, sc->lbvh, err);
+        built = builder == VMX_BVH_PLOC ? build_bvh_ploc_device(pos, nrm, uv, ntris, sc->leaf_size, device, sc->lbvh, err)
+                                        : build_bvh_lbvh_device(pos, nrm, uv, ntris, sc->leaf_size, device, sc->lbvh, err);
     } else {
         built = builder == VMX_BVH_SAH ? build_bvh_sah(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err)
                                        : build_bvh(pos, nrm, uv, ntris, sc->leaf_size, sc->bvh, err);
