@@ -47,9 +47,10 @@ bool HipIntegratorBase::upload(MeshEngine *mEng) {
     mScene = nullptr, mMulti = nullptr;
     // NULL,0 -> the reference's eight hard-coded spheres (meshEngine.cpp:377-500); leaf size 4 (bvh.h:29)
     const int rc = mDevices.size() > 1
-                       ? vmx_multi_create(pos.data(), nrm.data(), uv.data(), (uint32_t)faces, nullptr, 0, 4, VMX_BVH_REFERENCE,
+                       ? vmx_multi_create(pos.data(), nrm.data(), uv.data(), (uint32_t)faces, nullptr, 0, 4, mBuilder,
                                           mDevices.data(), (uint32_t)mDevices.size(), &mMulti)
-                       : vmx_scene_create(pos.data(), nrm.data(), uv.data(), (uint32_t)faces, nullptr, 0, 4, mDevices[0], &mScene);
+                       : vmx_scene_create_ex(pos.data(), nrm.data(), uv.data(), (uint32_t)faces, nullptr, 0, 4, mBuilder,
+                                             mDevices[0], &mScene);
     if (rc != VMX_OK) {
         std::fprintf(stderr, "vermilion_hip: %s\n", vmx_last_error());
         return false;

@@ -29,6 +29,13 @@ class HipIntegratorBase : public Integrator {
         if (mDevices.empty()) mDevices.push_back(0);
     }
     ~HipIntegratorBase() override;
+    // tree the library builds for the scene: VMX_BVH_REFERENCE (default: BVH::build's topology, the only one with
+    // the reference's triangle-ID / tie order), VMX_BVH_SAH, VMX_BVH_LBVH or VMX_BVH_PLOC (a quality tree built on
+    // the GPU in a few ms: 2.4x fewer node visits per ray).  Takes effect at the next upload.
+    void setBuilder(uint32_t builder) {
+        mBuilder = builder;
+        mUploadedFrom = nullptr;
+    }
 
    protected:
     bool upload(MeshEngine *mEng);
@@ -39,6 +46,7 @@ class HipIntegratorBase : public Integrator {
     int renderFrame(const vmx_camera &c, const vmx_opts &o, bool bruteForce, uint32_t flags, float *frame, vmx_stats *st);
     uint64_t mSeed;
     std::vector<int> mDevices;
+    uint32_t mBuilder = VMX_BVH_REFERENCE;
     vmx_scene *mScene = nullptr;   // one device
     vmx_multi *mMulti = nullptr;   // several
     const MeshEngine *mUploadedFrom = nullptr;
