@@ -1,6 +1,6 @@
 """Exactness arguments behind two kernel shortcuts, restated in numpy (CPU only).
 
-The three single-precision tests that let the kernels skip the double-precision sphere solve
+The four single-precision tests that let the kernels skip the double-precision sphere solve
 (vermilion_amd/csrc/vmx_kernels.hip: sphere_hit_op), restated in numpy and checked against the exact
 evaluation of the reference's formula (meshEngine.cpp:182-194): whenever a test fires, the exact result
 must be one RayCast ignores — 0, or not below the nearest distance so far.  Rays start inside the
@@ -36,11 +36,12 @@ def exact_and_shortcuts(o, d, centre, radius, lim):
         tol_m = (K_REL * ((C + r2).astype(f32) + BB).astype(f32)).astype(f32)
         tol_f = (K_REL * (((C + r2).astype(f32) + BB).astype(f32)
                           + (lim * ((f32(2) * np.abs(B)).astype(f32) + lim).astype(f32)).astype(f32)).astype(f32)).astype(f32)
-        far = (B > (lim * (f32(1) + K_REL)).astype(f32)) & \
-              ((X - (lim * ((f32(2) * B).astype(f32) - lim).astype(f32)).astype(f32)).astype(f32) > tol_f)
+        Y = (X - (lim * ((f32(2) * B).astype(f32) - lim).astype(f32)).astype(f32)).astype(f32)
+        far = (B > (lim * (f32(1) + K_REL)).astype(f32)) & (Y > tol_f)
         miss = BB < (X - tol_m).astype(f32)
         behind = (B < 0) & (B > -1e11) & (X > tol_m)
-    return th, miss | behind | far
+        inside_far = (X < -tol_m) & (Y < -tol_f)  # origin inside the sphere, its exit beyond the limit
+    return th, miss | behind | far | inside_far
 
 
 def check(o, d, rng):

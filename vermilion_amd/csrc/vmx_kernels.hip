@@ -364,7 +364,7 @@ __device__ __forceinline__ void tri_shading_normal(const SceneDev &sc, int slot,
 // sphereIntersect (meshEngine.cpp:182-194): float dots, float rad*rad, double discriminant.
 // The caller only uses a result in (0, limit) (limit = RayCast's nearest distance so far), and the
 // double-precision part (discriminant, square root, two roots: ~75 f64 instructions per sphere, 8
-// spheres per RayCast) was more than half of the shading kernels' time.  Three single-precision
+// spheres per RayCast) was more than half of the shading kernels' time.  Four single-precision
 // tests on the same float dot products B = op.d, C = op.op and R2 = rad*rad the reference forms
 // decide, with a margin far above every rounding error involved (2^-20 relative against 2^-24 float
 // and 2^-53 double steps), that the double-precision result cannot matter:
@@ -373,6 +373,10 @@ __device__ __forceinline__ void tri_shading_normal(const SceneDev &sc, int slot,
 //            of C (2^-53 C, ~0.3 for the wall spheres), so both roots are <= 1e-4 (|B| < 1e11): returns 0
 //   far    : B > limit and (C - R2) - limit (2B - limit) > tol  =>  det < (B - limit)^2 (1 - 2^-40),
 //            so the smaller root rounds to >= limit and the caller ignores it
+//   inside : (C - R2) < -tol (the origin is inside the sphere: the smaller root is negative, the result is the
+//            larger one) and (C - R2) - limit (2B - limit) < -tol  =>  limit lies between the roots, the larger
+//            root is > limit and the caller ignores it.  This is the common case of the reference's room: every
+//            ray starts inside four of its six 5e7-radius wall spheres and mostly ends on a triangle first
 // Only lanes that pass none of them need the exact evaluation; a wave runs it if any lane does (the
 // 64 camera rays of a wave belong to one pixel and mostly agree).
 // (op = centre - origin and C = op.op are passed in: for camera rays they are the same for every path
@@ -386,8 +390,10 @@ __device__ __forceinline__ float sphere_hit_op(float opx, float opy, float opz, 
     const float tol_f = kRel * (C + R2 + BB + limit * (2.f * fabsf(B) + limit));
     const bool miss = BB < X - tol_m;
     const bool behind = B < 0.f && B > -1e11f && X > tol_m;
-    const bool far = B > limit * (1.f + kRel) && (X - limit * (2.f * B - limit)) > tol_f;
-    const bool need = !(miss || behind || far);
+    const float Y = X - limit * (2.f * B - limit);  // limit^2 - 2 B limit + X: negative iff limit lies between the roots
+    const bool far = B > limit * (1.f + kRel) && Y > tol_f;
+    const bool inside_far = X < -tol_m && Y < -tol_f;
+    const bool need = !(miss || behind || far || inside_far);
     float th = 0.f;
     if (__builtin_amdgcn_ballot_w64(need) != 0) {
         const double b = (double)B;
