@@ -432,6 +432,10 @@ struct CastResult {
 // `geom`: optional copy of the spheres' (centre, rad*rad) in LDS (k_shade) — every path tests every
 // sphere, the rest of a sphere's record is read only when it becomes the nearest hit
 constexpr uint32_t kLdsSpheres = 16;
+static_assert(kLdsSpheres >= kMaxSpheres, "every sphere of a scene has an LDS slot");
+// LDS_GEOM / CAM_OP: compile-time, so that the table reads are plain LDS reads (a pointer chosen at run time
+// between LDS and global memory makes them flat loads); the API admits at most kLdsSpheres spheres
+template <bool LDS_GEOM = false, bool CAM_OP = false>
 __device__ __forceinline__ void cast_finish(const SceneDev &sc, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float best, int slot, CastResult &r,
                                             const float4 *geom = nullptr, const float4 *cam_op = nullptr) {
@@ -451,14 +455,14 @@ __device__ __forceinline__ void cast_finish(const SceneDev &sc, float ox, float 
     const uint32_t ns = sc.nspheres;
     for (uint32_t i = 0; i < ns; ++i) {
         float4 g;
-        if (geom != nullptr && i < kLdsSpheres) {
+        if (LDS_GEOM) {
             g = geom[i];
         } else {
             const SphereDev &q = sc.spheres[i];
             g = make_float4(q.cx, q.cy, q.cz, q.rad2);
         }
         float th;
-        if (cam_op != nullptr && i < kLdsSpheres) {  // (centre - camera, its squared length): camera rays only
+        if (CAM_OP) {  // (centre - camera, its squared length): camera rays only
             const float4 q = cam_op[i];
             th = sphere_hit_op(q.x, q.y, q.z, q.w, g.w, dx, dy, dz, r.nearest);
         } else {
@@ -1259,7 +1263,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                 if (shaded) {
                     depth0 = P.depth == 0 ? 1u : 0u;
                     CastResult c;
-                    cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, best, slot, c, s_geom);
+                    cast_finish<true, false>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, best, slot, c, s_geom);
                     fl.was_ray = is_ray;
                     alive = path_shade<TEX>(sc, fr.r2scale, P, c, fl);
                     if (!alive) {
@@ -2371,8 +2375,8 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             depth0 = P.depth == 0 ? 1u : 0u;
             fl.was_ray = depth0 ? true : finite3(P.dx, P.dy, P.dz);
             const float2 h = hits[pid];
-            cast_finish(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom,
-                        SRC == 0 ? s_cam_op : nullptr);
+            cast_finish<true, SRC == 0>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom,
+                                        s_cam_op);
             st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
             rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
         }
