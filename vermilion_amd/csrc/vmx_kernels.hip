@@ -2076,8 +2076,11 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                 }
                 lref = __float_as_uint(r3.x), rref = __float_as_uint(r3.y);
             } else {
-                const float4 q0 = inner[cur * 4], q1 = inner[cur * 4 + 1], q2 = inner[cur * 4 + 2];
-                const float2 q3 = ((const float2 *)inner)[cur * 8 + 6];
+                // (32-bit byte offset from a scalar base: the record tables are < 4 GB, and an index scaled in 64 bits
+                // costs two 64-bit VALU operations per fetch)
+                const float4 *rec = (const float4 *)((const char *)inner + (uint32_t)(cur << 6));
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                const float2 q3 = *(const float2 *)(rec + 3);
                 float a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5;
                 if (SRC == 0) {
                     a0 = q0.x * ix, a1 = q0.y * iy, a2 = q0.z * iz, a3 = q0.w * ix, a4 = q1.x * iy, a5 = q1.y * iz;
