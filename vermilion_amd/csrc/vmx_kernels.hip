@@ -1201,8 +1201,11 @@ __device__ __forceinline__ uint2 stack_pop(const uint2 *stk, const uint2 *ovf, i
     return e;
 }
 
+#ifndef VMX_PATHS_WPS
+#define VMX_PATHS_WPS 6  // waves per SIMD the fused kernel is compiled for (80 VGPRs): tail 8.8 -> 7.9 ms, early-stop frame 14.3 -> 13.8 ms (5: 8.1, 7: 8.4, 8: 8.9)
+#endif
 template <bool COUNT, int SRC, bool LOOP, bool TEX>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, VMX_PATHS_WPS)
 k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, float4 *__restrict__ rad,
         PathArrays pa, DevCounters *ctr) {
     extern __shared__ uint2 lds_stack[];
