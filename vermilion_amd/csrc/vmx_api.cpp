@@ -1230,7 +1230,9 @@ int bruteforce_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, 
         if (stats) std::memset(stats, 0, sizeof(*stats));
         return VMX_OK;
     }
-    if (ws.active[0].ensure(npix) || ws.counters.ensure(1)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the render workspace");
+    // rad doubles as the list of pixels that go on past the first samples (64 bytes each, at most every pixel)
+    if (ws.active[0].ensure(npix) || ws.counters.ensure(1) || ws.rad.ensure((size_t)npix * 64) || ws.next_count.ensure(32))
+        return fail(VMX_ERR_NOMEM, "hipMalloc failed for the render workspace");
     if (ws.order_w != W || ws.order_rows != rows) {
         tile_order(W, rows, ws.order);
         ws.order_w = W, ws.order_rows = rows;
@@ -1241,16 +1243,26 @@ int bruteforce_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, 
     if (!ev0 || !ev1) return fail(VMX_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipMemcpyAsync(ws.active[0].p, ws.order.data(), (size_t)npix * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
+    HIP_TRY(hipMemsetAsync(ws.next_count.p, 0, 4, s));
     HIP_TRY(hipEventRecord(ev0, s));
     LaunchCfg cfg = trace_cfg(sc, (npix + sc->block - 1) / sc->block, 4);
     TimedLaunch tl{ws.events.get(), ws.events.get(), 0, VMX_K_BRUTEFORCE};
     if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(tl.a, s));
-    LAUNCH_TRY(launch_bruteforce(sc->dev, fr, ws.active[0].p, npix, flags, d_out, ws.counters.p, cfg, s));
+    LAUNCH_TRY(launch_bruteforce(sc->dev, fr, ws.active[0].p, npix, flags, d_out, ws.counters.p, ws.rad.p, ws.next_count.p,
+                                 cfg, s));
+    uint64_t launches = 1;
+    unsigned int n_long = 0;  // pixels the break has not stopped within the first samples: a wave each from here
+    HIP_TRY(hipMemcpyAsync(&n_long, ws.next_count.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n_long != 0) {
+        LAUNCH_TRY(launch_bruteforce_long(sc->dev, fr, flags, d_out, ws.counters.p, ws.rad.p, ws.next_count.p, n_long, cfg, s));
+        launches++;
+    }
     HIP_TRY(hipEventRecord(tl.b, s));
     timed.push_back(tl);
     HIP_TRY(hipEventRecord(ev1, s));
-    return finish_stats(sc, s, timed, ev0, ev1, stats, 1, 1, t0);
+    return finish_stats(sc, s, timed, ev0, ev1, stats, 1, launches, t0);
 }
 
 }  // namespace

@@ -2555,107 +2555,156 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
 }
 
 // ---------------------------------------------------------------------------
-// k_bruteforce — BruteForceTracer::Render (core/integrators/integrators.cpp:9-186), the engine's
-// default integrator: one lane per pixel runs the reference's sample loop — jittered camera ray
-// (:65-81), RayCast, N.L against the point light (:83-88), normal perturbation by boundTextures[0]
-// (:98-106), the mirror probe (:119-137), albedo (:141-156), the convergence break (:166-172) —
-// and writes the pixel (:176-183).  Lanes are dealt 8x8-pixel tiles (the active list), so a wave's
-// rays are coherent; the break makes most pixels stop after 3 samples.  Jitters come from the
-// stream keyed (seed, pixel, sample) (the reference shares one unsynchronised std::mt19937, :30).
+// k_bruteforce / k_bruteforce_long — BruteForceTracer::Render (core/integrators/integrators.cpp:9-186), the
+// engine's default integrator: the reference's sample loop — jittered camera ray (:65-81), RayCast, N.L against
+// the point light (:83-88), normal perturbation by boundTextures[0] (:98-106), the mirror probe (:119-137),
+// albedo (:141-156), the convergence break (:166-172) — and the pixel write (:176-183).  Jitters come from the
+// stream keyed (seed, pixel, sample) (the reference shares one unsynchronised std::mt19937, :30), so a sample is
+// a function of (pixel, sample index) alone (bf_sample) and only the running sums and the break are sequential
+// (bf_fold).  Most pixels break after 3 samples, a few run to the last one: with one lane per pixel those few
+// set the frame time (186 ms at 256 spp, of which 25 ms is work).  So k_bruteforce (one lane per pixel, 8x8-pixel
+// tiles: coherent waves) takes the first kBfShort samples of every pixel and hands the pixels that have not
+// broken by then — with their sums — to k_bruteforce_long, where a WAVE takes a pixel: its 64 lanes evaluate 64
+// consecutive samples at once, lane 0 folds them in order, and the samples past the break are dropped.
 // ---------------------------------------------------------------------------
+struct BfSample {
+    float cx, cy, cz, dist;
+    uint32_t flags;  // 1: the camera ray hit something, 2: a triangle, 4: the mirror probe was a ray (finite direction)
+};
+struct BfState {
+    float ax, ay, az, aw;  // accum
+    float lx, ly, lz, lw;  // lastSampleColour
+    float dist;            // hitDistance of the last sample
+    uint32_t n;            // samples taken
+    uint32_t prim, sec, hits;
+};
+constexpr uint32_t kBfShort = 8;
+
+__device__ __forceinline__ BfSample bf_sample(const SceneDev &sc, const FrameDev &fr, uint32_t p, uint32_t sample,
+                                              uint2 *stk, Cnt &cnt) {
+    BfSample r = {0.f, 0.f, 0.f, 0.f, 0u};
+    Rng rng;
+    rng_init(rng, fr.seed, p, sample);
+    const float jx = rng_jitter(rng), jy = rng_jitter(rng);
+    const float hX = (float)((((double)((float)(p % fr.width) + jx) - 0.25) / (double)fr.width) * 2.0 - 1.0);   // :65
+    const float hY = (float)((((double)((float)(p / fr.width) + jy) - 0.25) / (double)fr.height) * 2.0 - 1.0);  // :66
+    const float bx = (float)((double)(hX * fr.sensor_x) * 0.5), by = (float)((double)(hY * fr.sensor_y) * 0.5);  // :73-74
+    const float gx = bx, gy = -by, gz = -fr.film_dist;  // :76
+    float dx = (fr.m[0] * gx + fr.m[3] * gy) + (fr.m[6] * gz + 0.0f);  // :79, GLM mat4*vec4 order
+    float dy = (fr.m[1] * gx + fr.m[4] * gy) + (fr.m[7] * gz + 0.0f);
+    float dz = (fr.m[2] * gx + fr.m[5] * gy) + (fr.m[8] * gz + 0.0f);
+    normalize3(dx, dy, dz);  // :81 (w == 1)
+    CastResult c;
+    ray_cast<false>(sc, fr.px, fr.py, fr.pz, dx, dy, dz, stk, c, cnt);
+    r.dist = c.nearest;  // *pHitDistance (meshEngine.cpp:507)
+    if (c.nearest < kInf) {
+        r.flags = 1u | (c.slot >= 0 ? 2u : 0u);
+        const float hx = fr.px + (dx * c.nearest), hy = fr.py + (dy * c.nearest), hz = fr.pz + (dz * c.nearest);
+        float nx = c.nx, ny = c.ny, nz = c.nz;
+        float Lx = 500.f - hx, Ly = 1100.f - hy, Lz = 2000.f - hz;  // :16,83
+        normalize3(Lx, Ly, Lz);                                     // :84
+        float unx = nx, uny = ny, unz = nz;
+        normalize3(unx, uny, unz);
+        float vNDL = dot3(Lx, Ly, Lz, unx, uny, unz);  // :88
+        if (sc.tex) {                                   // :98-106
+            const float4 t = tex_sample(sc, c.uvx, c.uvy);
+            nx = nx + t.x, ny = ny + t.y, nz = nz + t.z;
+            unx = nx, uny = ny, unz = nz;
+            normalize3(unx, uny, unz);
+            vNDL = dot3(Lx, Ly, Lz, unx, uny, unz);
+        }
+        // :119  -L - 2.f * N * dot(N, -L)
+        const float mLx = -Lx, mLy = -Ly, mLz = -Lz;
+        const float k = dot3(nx, ny, nz, mLx, mLy, mLz);
+        const float sx = mLx - (2.f * nx) * k, sy = mLy - (2.f * ny) * k, sz = mLz - (2.f * nz) * k;
+        if (finite3(sx, sy, sz)) r.flags |= 4u;
+        CastResult c2;
+        ray_cast<false>(sc, hx, hy, hz, sx, sy, sz, stk, c2, cnt);  // :121
+        if (!(c2.nearest < kInf)) {                                  // :133-137
+            vNDL = vNDL * 0.9f;
+            vNDL = vNDL + 0.1f;
+        }
+        if (sc.tex1) {  // :141-147
+            const float4 t = tex_sample_of(sc.tex1, sc.tex1_w, sc.tex1_h, sc.tex1_c, c.uvx, c.uvy);
+            r.cx = t.x * vNDL, r.cy = t.y * vNDL, r.cz = t.z * vNDL;
+        } else {  // :148-156
+            r.cx = 0.890196078f * vNDL, r.cy = 0.258823529f * vNDL, r.cz = 0.203921569f * vNDL;
+        }
+    }
+    return r;
+}
+
+// the sequential part of the sample loop (:59,158-173) for one sample; true = the convergence break fired
+__device__ __forceinline__ bool bf_fold(BfState &st, const BfSample &r, uint32_t flags) {
+    ++st.n;
+    ++st.prim;
+    st.dist = r.dist;
+    if (r.flags & 1u) {
+        if (r.flags & 2u) ++st.hits;
+        if (r.flags & 4u) ++st.sec;
+        st.ax = st.ax + r.cx, st.ay = st.ay + r.cy, st.az = st.az + r.cz, st.aw = st.aw + 1.0f;  // :158 (cw = 1)
+    }
+    const float fn = (float)st.n;
+    if (st.n > 2) {  // :167-172
+        st.lx = st.lx - st.ax / fn, st.ly = st.ly - st.ay / fn, st.lz = st.lz - st.az / fn, st.lw = st.lw - st.aw / fn;
+        const float sum = ((st.lx + st.ly) + st.lz) + st.lw;
+        float mag;
+        if (flags & 1u) {  // VMX_BF_ABS_INT: abs(int), the float truncated to int first
+            const double tr = trunc((double)sum);
+            mag = (tr >= -2147483648.0 && tr <= 2147483647.0) ? (float)abs((int)tr) : 0.f;
+        } else {
+            mag = fabsf(sum);
+        }
+        if (mag < 0.001f) return true;
+    }
+    st.lx = st.ax / fn, st.ly = st.ay / fn, st.lz = st.az / fn, st.lw = st.aw / fn;  // :173
+    return false;
+}
+
+__device__ __forceinline__ void bf_write_pixel(const BfState &st, float *__restrict__ out, uint32_t lp) {
+    const float fn = (float)st.n;
+    float *o5 = out + (size_t)lp * 5;  // :176-183
+    o5[0] = sel_max(sel_min(st.ax / fn, 1.f), 0.f);  // std::max(std::min(x, 1.f), 0.f), NaN and all
+    o5[1] = sel_max(sel_min(st.ay / fn, 1.f), 0.f);
+    o5[2] = sel_max(sel_min(st.az / fn, 1.f), 0.f);
+    o5[3] = st.aw / fn;
+    o5[4] = st.dist;
+}
+
+// a pixel handed from k_bruteforce to k_bruteforce_long: 16 dwords
+struct BfLong {
+    uint32_t lp, n;
+    float ax, ay, az, aw, lx, ly, lz, lw, dist;
+    uint32_t pad[5];
+};
+
 __global__ void __launch_bounds__(256)
 k_bruteforce(SceneDev sc, FrameDev fr, const unsigned int *__restrict__ order, uint32_t npix, uint32_t flags,
-             float *__restrict__ out, DevCounters *ctr) {
+             float *__restrict__ out, DevCounters *ctr, BfLong *__restrict__ longs, unsigned int *long_count) {
     extern __shared__ uint2 lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
     Cnt cnt = {0, 0};
     uint32_t n_prim = 0, n_sec = 0, n_hits = 0, n_samples = 0;
+    const uint32_t cap = min(fr.spp, kBfShort);
     for (uint32_t base = blockIdx.x * blockDim.x; base < npix; base += gridDim.x * blockDim.x) {
         const uint32_t i = base + threadIdx.x;
         if (i >= npix) continue;
         const uint32_t lp = order[i];
         const uint32_t p = global_pixel(fr, lp);
-        float hitDistance = 0.f;
-        float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;      // accum
-        float lx = 0.f, ly = 0.f, lz = 0.f, lw = 0.f;      // lastSampleColour
-        float cx = 0.f, cy = 0.f, cz = 0.f, cw = 0.f;      // currentSampleColour
-        uint32_t n = 0;
-        for (uint32_t sample = 0; sample < fr.spp; ++sample) {  // :59
-            ++n;
-            Rng rng;
-            rng_init(rng, fr.seed, p, sample);
-            const float jx = rng_jitter(rng), jy = rng_jitter(rng);
-            const float hX = (float)((((double)((float)(p % fr.width) + jx) - 0.25) / (double)fr.width) * 2.0 - 1.0);   // :65
-            const float hY = (float)((((double)((float)(p / fr.width) + jy) - 0.25) / (double)fr.height) * 2.0 - 1.0);  // :66
-            const float bx = (float)((double)(hX * fr.sensor_x) * 0.5), by = (float)((double)(hY * fr.sensor_y) * 0.5);  // :73-74
-            const float gx = bx, gy = -by, gz = -fr.film_dist;  // :76
-            float dx = (fr.m[0] * gx + fr.m[3] * gy) + (fr.m[6] * gz + 0.0f);  // :79, GLM mat4*vec4 order
-            float dy = (fr.m[1] * gx + fr.m[4] * gy) + (fr.m[7] * gz + 0.0f);
-            float dz = (fr.m[2] * gx + fr.m[5] * gy) + (fr.m[8] * gz + 0.0f);
-            normalize3(dx, dy, dz);  // :81 (w == 1)
-            ++n_prim;
-            CastResult c;
-            ray_cast<false>(sc, fr.px, fr.py, fr.pz, dx, dy, dz, stk, c, cnt);
-            hitDistance = c.nearest;  // *pHitDistance (meshEngine.cpp:507)
-            if (c.nearest < kInf) {
-                if (c.slot >= 0) ++n_hits;
-                const float hx = fr.px + (dx * c.nearest), hy = fr.py + (dy * c.nearest), hz = fr.pz + (dz * c.nearest);
-                float nx = c.nx, ny = c.ny, nz = c.nz;
-                float Lx = 500.f - hx, Ly = 1100.f - hy, Lz = 2000.f - hz;  // :16,83
-                normalize3(Lx, Ly, Lz);                                     // :84
-                float unx = nx, uny = ny, unz = nz;
-                normalize3(unx, uny, unz);
-                float vNDL = dot3(Lx, Ly, Lz, unx, uny, unz);  // :88
-                if (sc.tex) {                                   // :98-106
-                    const float4 t = tex_sample(sc, c.uvx, c.uvy);
-                    nx = nx + t.x, ny = ny + t.y, nz = nz + t.z;
-                    unx = nx, uny = ny, unz = nz;
-                    normalize3(unx, uny, unz);
-                    vNDL = dot3(Lx, Ly, Lz, unx, uny, unz);
-                }
-                // :119  -L - 2.f * N * dot(N, -L)
-                const float mLx = -Lx, mLy = -Ly, mLz = -Lz;
-                const float k = dot3(nx, ny, nz, mLx, mLy, mLz);
-                const float sx = mLx - (2.f * nx) * k, sy = mLy - (2.f * ny) * k, sz = mLz - (2.f * nz) * k;
-                if (finite3(sx, sy, sz)) ++n_sec;
-                CastResult c2;
-                ray_cast<false>(sc, hx, hy, hz, sx, sy, sz, stk, c2, cnt);  // :121
-                if (!(c2.nearest < kInf)) {                                  // :133-137
-                    vNDL = vNDL * 0.9f;
-                    vNDL = vNDL + 0.1f;
-                }
-                if (sc.tex1) {  // :141-147
-                    const float4 t = tex_sample_of(sc.tex1, sc.tex1_w, sc.tex1_h, sc.tex1_c, c.uvx, c.uvy);
-                    cx = t.x * vNDL, cy = t.y * vNDL, cz = t.z * vNDL, cw = 1.0f;
-                } else {  // :148-156
-                    cx = 0.890196078f * vNDL, cy = 0.258823529f * vNDL, cz = 0.203921569f * vNDL, cw = 1.0f;
-                }
-                ax = ax + cx, ay = ay + cy, az = az + cz, aw = aw + cw;  // :158
-            }
-            const float fn = (float)n;
-            if (n > 2) {  // :167-172
-                lx = lx - ax / fn, ly = ly - ay / fn, lz = lz - az / fn, lw = lw - aw / fn;
-                const float sum = ((lx + ly) + lz) + lw;
-                float mag;
-                if (flags & 1u) {  // VMX_BF_ABS_INT: abs(int), the float truncated to int first
-                    const double tr = trunc((double)sum);
-                    mag = (tr >= -2147483648.0 && tr <= 2147483647.0) ? (float)abs((int)tr) : 0.f;
-                } else {
-                    mag = fabsf(sum);
-                }
-                if (mag < 0.001f) break;
-            }
-            lx = ax / fn, ly = ay / fn, lz = az / fn, lw = aw / fn;  // :173
+        BfState st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u};
+        bool broke = false;
+        for (uint32_t sample = 0; sample < cap && !broke; ++sample)  // :59
+            broke = bf_fold(st, bf_sample(sc, fr, p, sample, stk, cnt), flags);
+        n_prim += st.prim, n_sec += st.sec, n_hits += st.hits;
+        if (broke || st.n >= fr.spp) {
+            n_samples += st.n;
+            bf_write_pixel(st, out, lp);
+        } else {  // not converged yet: a wave of k_bruteforce_long goes on from here
+            const uint32_t at = atomicAdd(long_count, 1u);
+            BfLong rec = {lp, st.n, st.ax, st.ay, st.az, st.aw, st.lx, st.ly, st.lz, st.lw, st.dist, {0, 0, 0, 0, 0}};
+            longs[at] = rec;
         }
-        n_samples += n;
-        const float fn = (float)n;
-        float *o5 = out + (size_t)lp * 5;  // :176-183
-        o5[0] = sel_max(sel_min(ax / fn, 1.f), 0.f);  // std::max(std::min(x, 1.f), 0.f), NaN and all
-        o5[1] = sel_max(sel_min(ay / fn, 1.f), 0.f);
-        o5[2] = sel_max(sel_min(az / fn, 1.f), 0.f);
-        o5[3] = aw / fn;
-        o5[4] = hitDistance;
     }
     const uint32_t wp = wave_sum(n_prim), ws = wave_sum(n_sec), wh = wave_sum(n_hits), wn = wave_sum(n_samples);
     if (lane == 0) {
@@ -2665,6 +2714,48 @@ k_bruteforce(SceneDev sc, FrameDev fr, const unsigned int *__restrict__ order, u
         if (wn) atomicAdd(&ctr->samples, (unsigned long long)wn);
     }
 }
+
+__global__ void __launch_bounds__(256)
+k_bruteforce_long(SceneDev sc, FrameDev fr, uint32_t flags, float *__restrict__ out, DevCounters *ctr,
+                  const BfLong *__restrict__ longs, const unsigned int *long_count) {
+    extern __shared__ uint2 lds_stack[];
+    __shared__ BfSample s_res[4][64];
+    __shared__ uint32_t s_stop[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    Cnt cnt = {0, 0};
+    const uint32_t total = *long_count, waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t e = blockIdx.x * (blockDim.x >> 6) + wave; e < total; e += waves) {
+        const BfLong rec = longs[e];
+        const uint32_t p = global_pixel(fr, rec.lp);
+        BfState st = {rec.ax, rec.ay, rec.az, rec.aw, rec.lx, rec.ly, rec.lz, rec.lw, rec.dist, rec.n, 0u, 0u, 0u};
+        uint32_t next = rec.n;  // the next sample index (= samples taken so far)
+        bool broke = false;
+        while (!broke && next < fr.spp) {
+            const uint32_t count = min(64u, fr.spp - next);
+            if (lane < count) s_res[wave][lane] = bf_sample(sc, fr, p, next + lane, stk, cnt);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (lane == 0) {
+                uint32_t j = 0;
+                for (; j < count && !broke; ++j) broke = bf_fold(st, s_res[wave][j], flags);
+                s_stop[wave] = broke ? 1u : 0u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            broke = s_stop[wave] != 0u;
+            next += count;
+        }
+        if (lane == 0) {
+            bf_write_pixel(st, out, rec.lp);
+            if (st.prim) atomicAdd(&ctr->stage[0].rays, (unsigned long long)st.prim);
+            if (st.sec) atomicAdd(&ctr->stage[1].rays, (unsigned long long)st.sec);
+            if (st.hits) atomicAdd(&ctr->stage[0].tri_hits, (unsigned long long)st.hits);
+            atomicAdd(&ctr->samples, (unsigned long long)st.n);
+        }
+    }
+}
+
 
 __global__ void k_assemble(const float *__restrict__ gathered, uint64_t rank_stride, uint32_t width,
                            uint32_t height, uint32_t stripe_rows, uint32_t world, float *__restrict__ frame) {
@@ -2924,9 +3015,17 @@ int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_ac
 }
 
 int launch_bruteforce(const SceneDev &sc, const FrameDev &fr, const unsigned int *order, uint32_t npix, uint32_t flags,
-                      float *out, DevCounters *counters, LaunchCfg cfg, void *stream) {
+                      float *out, DevCounters *counters, void *longs, unsigned int *long_count, LaunchCfg cfg, void *stream) {
     hipLaunchKernelGGL(k_bruteforce, dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, (hipStream_t)stream, sc, fr, order,
-                       npix, flags, out, counters);
+                       npix, flags, out, counters, (BfLong *)longs, long_count);
+    return launch_status();
+}
+// the pixels k_bruteforce handed over (*long_count of them, known to the host as `count`): one wave each
+int launch_bruteforce_long(const SceneDev &sc, const FrameDev &fr, uint32_t flags, float *out, DevCounters *counters,
+                           const void *longs, const unsigned int *long_count, uint32_t count, LaunchCfg cfg, void *stream) {
+    const uint32_t blocks = std::min<uint32_t>(cfg.grid, (count + (cfg.block / 64) - 1) / (cfg.block / 64));
+    hipLaunchKernelGGL(k_bruteforce_long, dim3(std::max(blocks, 1u)), dim3(cfg.block), cfg.lds_bytes, (hipStream_t)stream, sc, fr,
+                       flags, out, counters, (const BfLong *)longs, long_count);
     return launch_status();
 }
 
