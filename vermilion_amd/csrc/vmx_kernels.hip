@@ -1785,6 +1785,11 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 //   * the all-lanes-idle test is made once per 8 steps, not every step.
 // Each ray still performs exactly the reference's sequence of tests (bvh.cpp:47-145).
 // ---------------------------------------------------------------------------
+#ifdef VMX_STEP_PROFILE
+#define VMX_DESCENT_COUNT "s_add_u32 %[done], %[done], 1\n\ts_nop 0\n\t"  // nodes done, for tools/step_profile.py
+#else
+#define VMX_DESCENT_COUNT "s_nop 1\n\t"  // the product does not count them: a scalar instruction is an issue slot
+#endif
 // ---------------------------------------------------------------------------
 // uniform_descent — camera rays: the stretch of a traversal in which all traversing lanes of a wave are at
 // the same inner node and take the same child, as one assembly loop.
@@ -1812,7 +1817,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 // general step goes on from there; a leaf, or a lane whose next push would leave the LDS levels, ends the
 // loop as well.  Every ray performs exactly the tests of the general step, in the same order.
 //   in: trav = the traversing lanes, scur = the inner node they all are at, sp < lds_entries in each of them
-//   out: cur (per lane: next node, leaf or kPop), sp; returns the number of nodes done
+//   out: cur (per lane: next node, leaf or kPop), sp; returns the number of nodes done (diagnostic build; else 0)
 // The record lives in s[36:51] (an inline-asm operand cannot be a 16-register tuple).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, float ix, float iy, float iz, float best,
@@ -1846,8 +1851,7 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
         "v_mul_f32_e32 %[t2], s47, %[iz]\n\t"
         "v_min3_f32 %[tf], %[t0], %[t1], %[t2]\n\t"
         "v_cmp_le_f32_e32 vcc, %[n1], %[tf]\n\t"              // right child hit
-        "s_add_u32 %[done], %[done], 1\n\t"
-        "s_nop 0\n\t"
+        VMX_DESCENT_COUNT  // (two wait states between the compare and the select on its mask either way)
         "v_cndmask_b32_e32 %[n1], %[inf], %[n1], vcc\n\t"
         "v_cmp_lt_f32_e32 vcc, %[n1], %[n0]\n\t"              // go right: strictly closer, or the only one hit (bvh.cpp:106)
         "v_min_f32_e32 %[near], %[n0], %[n1]\n\t"
@@ -2280,7 +2284,12 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
 #endif
                         const uint32_t done = uniform_descent(sp, cur, ix, iy, iz, best, (uint32_t)(uintptr_t)stk, uni_base,
                                                               c0, lds_entries, trav);
+#ifdef VMX_STEP_PROFILE
                         act += (int)done;
+#else
+                        (void)done;
+                        act += 4;  // about what a descent takes (4.7 nodes on the bench frame); the batch only paces the refill test
+#endif
 #ifdef VMX_STEP_PROFILE
                         if (lane == 0) {
                             s_prof[wave][7][0] += __builtin_readcyclecounter() - t0_;
