@@ -1245,18 +1245,25 @@ int bruteforce_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, 
     HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
     HIP_TRY(hipMemsetAsync(ws.next_count.p, 0, 4, s));
     HIP_TRY(hipEventRecord(ev0, s));
-    LaunchCfg cfg = trace_cfg(sc, (npix + sc->block - 1) / sc->block, 4);
+    // stack as in the traversal kernels: a few levels per lane in LDS, the rest in the global slab (the whole stack
+    // in LDS leaves room for 3 waves per SIMD: 28 -> 20 ms for the 16-spp frame)
+    const Tuning tn = make_tuning(sc, &o);
+    LaunchCfg cfg = paths_cfg(sc, tn.lds_entries, (uint64_t)npix, 5);
+    WorkDev stack;
+    std::memset(&stack, 0, sizeof(stack));
+    rc = bind_stack(sc, tn, tn.lds_entries, cfg.grid, (uint64_t)npix, stack);
+    if (rc) return rc;
     TimedLaunch tl{ws.events.get(), ws.events.get(), 0, VMX_K_BRUTEFORCE};
     if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(tl.a, s));
     LAUNCH_TRY(launch_bruteforce(sc->dev, fr, ws.active[0].p, npix, flags, d_out, ws.counters.p, ws.rad.p, ws.next_count.p,
-                                 cfg, s));
+                                 stack, cfg, s));
     uint64_t launches = 1;
     unsigned int n_long = 0;  // pixels the break has not stopped within the first samples: a wave each from here
     HIP_TRY(hipMemcpyAsync(&n_long, ws.next_count.p, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (n_long != 0) {
-        LAUNCH_TRY(launch_bruteforce_long(sc->dev, fr, flags, d_out, ws.counters.p, ws.rad.p, ws.next_count.p, n_long, cfg, s));
+        LAUNCH_TRY(launch_bruteforce_long(sc->dev, fr, flags, d_out, ws.counters.p, ws.rad.p, ws.next_count.p, n_long, stack, cfg, s));
         launches++;
     }
     HIP_TRY(hipEventRecord(tl.b, s));

@@ -124,9 +124,10 @@ int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_ac
 // BruteForceTracer::Render (integrators.cpp:9-186): one lane per pixel of `order` (tile-ordered local pixels)
 int launch_bruteforce(const SceneDev &sc, const FrameDev &fr, const unsigned int *order, uint32_t npix, uint32_t flags,
                       float *out, DevCounters *counters, void *longs /* 64 bytes per pixel */, unsigned int *long_count,
-                      LaunchCfg cfg, void *stream);
+                      const WorkDev &stack /* lds_entries, overflow_entries, overflow_stack */, LaunchCfg cfg, void *stream);
 int launch_bruteforce_long(const SceneDev &sc, const FrameDev &fr, uint32_t flags, float *out, DevCounters *counters,
-                           const void *longs, const unsigned int *long_count, uint32_t count, LaunchCfg cfg, void *stream);
+                           const void *longs, const unsigned int *long_count, uint32_t count, const WorkDev &stack,
+                           LaunchCfg cfg, void *stream);
 int launch_quantize(const float *frame, uint64_t npix, void *rgba8, float *depth, void *stream);
 int launch_assemble(const float *gathered, uint64_t rank_stride_floats, uint32_t width, uint32_t height,
                     uint32_t stripe_rows, uint32_t world, float *frame, void *stream);

@@ -236,10 +236,15 @@ __device__ __forceinline__ void box_net_exact(float t0x, float t0y, float t0z, f
 // BVH::getIntersection, nearest hit (bvh.cpp:47-145) + Triangle::getIntersection
 // (triangle.cpp:4-54).  `stk` points at this lane's column of the wave's LDS stack.
 // ---------------------------------------------------------------------------
+// (per-lane traversal stack helpers, defined with the persistent kernels below)
+__device__ __forceinline__ void stack_push(uint2 *stk, uint2 *ovf, int lds_entries, int sp, uint2 e);
+__device__ __forceinline__ uint2 stack_pop(const uint2 *stk, const uint2 *ovf, int lds_entries, int sp);
+
 template <bool COUNT>
 __device__ __forceinline__ void bvh_nearest(const SceneDev &sc, float ox, float oy, float oz, float dx,
                                             float dy, float dz, uint2 *stk, float &best_out,
-                                            int &slot_out, Cnt &cnt) {
+                                            int &slot_out, Cnt &cnt, uint2 *ovf = nullptr,
+                                            int lds_entries = 0x7FFFFFFF /* levels of `stk` in LDS; deeper ones in `ovf` */) {
     const float4 *__restrict__ inner = (const float4 *)sc.inner;
     const float4 *__restrict__ tris = (const float4 *)sc.tris;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;  // Ray.h:10
@@ -255,7 +260,7 @@ __device__ __forceinline__ void bvh_nearest(const SceneDev &sc, float ox, float 
         if (!have) {
             if (sp == 0) break;
             --sp;
-            const uint2 e = stk[sp * 64];
+            const uint2 e = stack_pop(stk, ovf, lds_entries, sp);
             cur = e.x;
             cur_near = __uint_as_float(e.y);
         }
@@ -308,7 +313,7 @@ __device__ __forceinline__ void bvh_nearest(const SceneDev &sc, float ox, float 
                 const bool sw = tn1 < tn0;
                 const uint32_t closer = sw ? rref : lref, other = sw ? lref : rref;
                 const float nc = sw ? tn1 : tn0, no = sw ? tn0 : tn1;
-                stk[sp * 64] = make_uint2(other, __float_as_uint(no));  // farther first (bvh.cpp:120)
+                stack_push(stk, ovf, lds_entries, sp, make_uint2(other, __float_as_uint(no)));  // farther first (bvh.cpp:120)
                 ++sp;
                 cur = closer;
                 cur_near = nc;
@@ -488,10 +493,11 @@ __device__ __forceinline__ void cast_finish(const SceneDev &sc, float ox, float 
 // MeshEngine::RayCast (meshEngine.cpp:239-509)
 template <bool COUNT>
 __device__ __forceinline__ void ray_cast(const SceneDev &sc, float ox, float oy, float oz, float dx,
-                                         float dy, float dz, uint2 *stk, CastResult &r, Cnt &cnt) {
+                                         float dy, float dz, uint2 *stk, CastResult &r, Cnt &cnt, uint2 *ovf = nullptr,
+                                         int lds_entries = 0x7FFFFFFF) {
     float best;
     int slot;
-    bvh_nearest<COUNT>(sc, ox, oy, oz, dx, dy, dz, stk, best, slot, cnt);
+    bvh_nearest<COUNT>(sc, ox, oy, oz, dx, dy, dz, stk, best, slot, cnt, ovf, lds_entries);
     cast_finish(sc, ox, oy, oz, dx, dy, dz, best, slot, r);
 }
 
@@ -2590,7 +2596,7 @@ struct BfState {
 constexpr uint32_t kBfShort = 8;
 
 __device__ __forceinline__ BfSample bf_sample(const SceneDev &sc, const FrameDev &fr, uint32_t p, uint32_t sample,
-                                              uint2 *stk, Cnt &cnt) {
+                                              uint2 *stk, uint2 *ovf, int lds_entries, Cnt &cnt) {
     BfSample r = {0.f, 0.f, 0.f, 0.f, 0u};
     Rng rng;
     rng_init(rng, fr.seed, p, sample);
@@ -2604,7 +2610,7 @@ __device__ __forceinline__ BfSample bf_sample(const SceneDev &sc, const FrameDev
     float dz = (fr.m[2] * gx + fr.m[5] * gy) + (fr.m[8] * gz + 0.0f);
     normalize3(dx, dy, dz);  // :81 (w == 1)
     CastResult c;
-    ray_cast<false>(sc, fr.px, fr.py, fr.pz, dx, dy, dz, stk, c, cnt);
+    ray_cast<false>(sc, fr.px, fr.py, fr.pz, dx, dy, dz, stk, c, cnt, ovf, lds_entries);
     r.dist = c.nearest;  // *pHitDistance (meshEngine.cpp:507)
     if (c.nearest < kInf) {
         r.flags = 1u | (c.slot >= 0 ? 2u : 0u);
@@ -2628,7 +2634,7 @@ __device__ __forceinline__ BfSample bf_sample(const SceneDev &sc, const FrameDev
         const float sx = mLx - (2.f * nx) * k, sy = mLy - (2.f * ny) * k, sz = mLz - (2.f * nz) * k;
         if (finite3(sx, sy, sz)) r.flags |= 4u;
         CastResult c2;
-        ray_cast<false>(sc, hx, hy, hz, sx, sy, sz, stk, c2, cnt);  // :121
+        ray_cast<false>(sc, hx, hy, hz, sx, sy, sz, stk, c2, cnt, ovf, lds_entries);  // :121
         if (!(c2.nearest < kInf)) {                                  // :133-137
             vNDL = vNDL * 0.9f;
             vNDL = vNDL + 0.1f;
@@ -2689,10 +2695,15 @@ struct BfLong {
 
 __global__ void __launch_bounds__(256)
 k_bruteforce(SceneDev sc, FrameDev fr, const unsigned int *__restrict__ order, uint32_t npix, uint32_t flags,
-             float *__restrict__ out, DevCounters *ctr, BfLong *__restrict__ longs, unsigned int *long_count) {
+             float *__restrict__ out, DevCounters *ctr, BfLong *__restrict__ longs, unsigned int *long_count,
+             uint32_t lds_levels, uint32_t overflow_entries, void *overflow_stack) {
+    // (stack: lds_levels per lane in LDS, deeper entries in the global slab, as in the traversal kernels — the
+    // whole stack in LDS leaves room for 3 waves per SIMD)
     extern __shared__ uint2 lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    const int lds_entries = (int)lds_levels;
+    uint2 *stk = lds_stack + (size_t)wave * (lds_levels + 1) * 64 + lane;
+    uint2 *ovf = (uint2 *)overflow_stack + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * overflow_entries) * 64 + lane;
     Cnt cnt = {0, 0};
     uint32_t n_prim = 0, n_sec = 0, n_hits = 0, n_samples = 0;
     const uint32_t cap = min(fr.spp, kBfShort);
@@ -2704,7 +2715,7 @@ k_bruteforce(SceneDev sc, FrameDev fr, const unsigned int *__restrict__ order, u
         BfState st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u, 0u, 0u};
         bool broke = false;
         for (uint32_t sample = 0; sample < cap && !broke; ++sample)  // :59
-            broke = bf_fold(st, bf_sample(sc, fr, p, sample, stk, cnt), flags);
+            broke = bf_fold(st, bf_sample(sc, fr, p, sample, stk, ovf, lds_entries, cnt), flags);
         n_prim += st.prim, n_sec += st.sec, n_hits += st.hits;
         if (broke || st.n >= fr.spp) {
             n_samples += st.n;
@@ -2726,12 +2737,15 @@ k_bruteforce(SceneDev sc, FrameDev fr, const unsigned int *__restrict__ order, u
 
 __global__ void __launch_bounds__(256)
 k_bruteforce_long(SceneDev sc, FrameDev fr, uint32_t flags, float *__restrict__ out, DevCounters *ctr,
-                  const BfLong *__restrict__ longs, const unsigned int *long_count) {
+                  const BfLong *__restrict__ longs, const unsigned int *long_count, uint32_t lds_levels,
+                  uint32_t overflow_entries, void *overflow_stack) {
     extern __shared__ uint2 lds_stack[];
     __shared__ BfSample s_res[4][64];
     __shared__ uint32_t s_stop[4];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
+    const int lds_entries = (int)lds_levels;
+    uint2 *stk = lds_stack + (size_t)wave * (lds_levels + 1) * 64 + lane;
+    uint2 *ovf = (uint2 *)overflow_stack + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * overflow_entries) * 64 + lane;
     Cnt cnt = {0, 0};
     const uint32_t total = *long_count, waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t e = blockIdx.x * (blockDim.x >> 6) + wave; e < total; e += waves) {
@@ -2742,7 +2756,7 @@ k_bruteforce_long(SceneDev sc, FrameDev fr, uint32_t flags, float *__restrict__ 
         bool broke = false;
         while (!broke && next < fr.spp) {
             const uint32_t count = min(64u, fr.spp - next);
-            if (lane < count) s_res[wave][lane] = bf_sample(sc, fr, p, next + lane, stk, cnt);
+            if (lane < count) s_res[wave][lane] = bf_sample(sc, fr, p, next + lane, stk, ovf, lds_entries, cnt);
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (lane == 0) {
@@ -3024,17 +3038,21 @@ int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_ac
 }
 
 int launch_bruteforce(const SceneDev &sc, const FrameDev &fr, const unsigned int *order, uint32_t npix, uint32_t flags,
-                      float *out, DevCounters *counters, void *longs, unsigned int *long_count, LaunchCfg cfg, void *stream) {
+                      float *out, DevCounters *counters, void *longs, unsigned int *long_count, const WorkDev &stack,
+                      LaunchCfg cfg, void *stream) {
     hipLaunchKernelGGL(k_bruteforce, dim3(cfg.grid), dim3(cfg.block), cfg.lds_bytes, (hipStream_t)stream, sc, fr, order,
-                       npix, flags, out, counters, (BfLong *)longs, long_count);
+                       npix, flags, out, counters, (BfLong *)longs, long_count, stack.lds_entries, stack.overflow_entries,
+                       stack.overflow_stack);
     return launch_status();
 }
 // the pixels k_bruteforce handed over (*long_count of them, known to the host as `count`): one wave each
 int launch_bruteforce_long(const SceneDev &sc, const FrameDev &fr, uint32_t flags, float *out, DevCounters *counters,
-                           const void *longs, const unsigned int *long_count, uint32_t count, LaunchCfg cfg, void *stream) {
+                           const void *longs, const unsigned int *long_count, uint32_t count, const WorkDev &stack,
+                           LaunchCfg cfg, void *stream) {
     const uint32_t blocks = std::min<uint32_t>(cfg.grid, (count + (cfg.block / 64) - 1) / (cfg.block / 64));
     hipLaunchKernelGGL(k_bruteforce_long, dim3(std::max(blocks, 1u)), dim3(cfg.block), cfg.lds_bytes, (hipStream_t)stream, sc, fr,
-                       flags, out, counters, (const BfLong *)longs, long_count);
+                       flags, out, counters, (const BfLong *)longs, long_count, stack.lds_entries, stack.overflow_entries,
+                       stack.overflow_stack);
     return launch_status();
 }
 
