@@ -158,6 +158,17 @@ def main():
         es_k = max(1, min(args.steps, 3))
         es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
 
+    # §8 f-4: the engine's default integrator on the same scene and camera (BruteForceTracer, most pixels stop after
+    # 3 samples): device time of one frame
+    bf_info = None
+    if world == 1 and not args.no_extras:
+        bopts = va.make_opts(seed=args.seed)
+        sc.render_bruteforce(cam, bopts)
+        _, bst = sc.render_bruteforce(cam, bopts)
+        bf_info = {"what": "BruteForceTracer::Render (integrators.cpp:9-186) of the same scene and camera, device time",
+                   "ms_per_frame": round(bst["ms_device"], 3), "samples": int(bst["samples"]),
+                   "Mrays_per_s": round((bst["rays_primary"] + bst["rays_secondary"]) / bst["ms_device"] / 1e3, 2)}
+
     # §8 f-1 quality builder (binned SAH, not the reference's topology): same frame, extra figure only
     q_info = None
     if world == 1 and not args.no_extras:
@@ -317,6 +328,8 @@ def main():
         if q_info:
             out["quality_bvh"] = q_info
             out["quality_bvh_gpu_built"] = p_info
+        if bf_info:
+            out["bruteforce_frame"] = bf_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, nrm, uv, c, W, H, args.cpu_spp, args.seed)
         print(json.dumps(out), flush=True)
