@@ -568,6 +568,19 @@ def test_lbvh_scene_creation_is_a_per_frame_operation_f1():
         g.close()
 
 
+def test_device_builders_are_deterministic_f1():
+    """every choice in the device builders is a sort, a scan or a strict total order (ties between equal Morton
+    codes / equal merge costs are broken by position), so two builds of the same scene give the same tree"""
+    pos, nrm, uv = scenes.bunny70k()
+    for bld in (va._lib.VMX_BVH_LBVH, va._lib.VMX_BVH_PLOC):
+        trees = []
+        for _ in range(2):
+            with va.Scene(pos, nrm, uv, builder=bld) as sc:
+                trees.append(sc.bvh())
+        for k in trees[0]:
+            assert np.array_equal(trees[0][k], trees[1][k]), (bld, k)
+
+
 def _random_soup(rng, n, kind):
     """triangle soups that stress the tree and the traversal: flat axis-aligned sheets (zero-thickness boxes),
     duplicated triangles (exact distance ties), slivers and degenerate (zero-area) triangles, huge + tiny mixed"""
