@@ -568,6 +568,39 @@ def test_lbvh_scene_creation_is_a_per_frame_operation_f1():
         g.close()
 
 
+def test_large_scene_two_million_triangles():
+    """a scene 8x the bench scene's size: record offsets beyond 2^27 bytes, a deeper tree, every builder"""
+    rng = np.random.default_rng(77)
+    n = 2_000_000
+    c = rng.uniform((-1400, 20, -850), (1400, 950, 850), (n, 1, 3)).astype(np.float32)
+    pos = np.ascontiguousarray(c + rng.uniform(-6, 6, (n, 3, 3)).astype(np.float32))
+    nr = np.cross(pos[:, 1] - pos[:, 0], pos[:, 2] - pos[:, 0]).astype(np.float32)
+    nr /= np.maximum(np.linalg.norm(nr, axis=1, keepdims=True), 1e-20)
+    nrm = np.repeat(nr[:, None, :], 3, axis=1).copy()
+    o, d = rand_rays(150000, 5)
+    cam = va.make_camera((0.0, 400.0, 1700.0), (0.0, 0.0, 0.0), 96, 54, 64)
+    p = Pair(pos, nrm, None)
+    g, c2 = p.gpu.bvh(), p.cpu.bvh()
+    for k in g:
+        assert np.array_equal(g[k], c2[k]), k
+    tri, t = p.gpu.trace(o, d)
+    rtri, rt = p.cpu.trace(o, d)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    assert (tri >= 0).mean() > 0.5
+    ref, _ = p.cpu.render(cam, va.make_opts(seed=2, early_stop=False))
+    for kw in ({}, {"pipeline": 4, "tail_threshold": 1}):
+        img, _ = p.gpu.render(cam, va.make_opts(seed=2, early_stop=False, **kw))
+        assert np.array_equal(bits(img), bits(ref)), kw
+    p.close()
+    for bld in (va._lib.VMX_BVH_LBVH, va._lib.VMX_BVH_PLOC):
+        with va.Scene(pos, nrm, None, builder=bld) as sc:
+            osc = O.OracleScene(pos, nrm, None, tree=sc.bvh())
+            tri, t = sc.trace(o, d)
+            otri, ot = osc.trace(o, d)
+            assert np.array_equal(tri, otri) and np.array_equal(bits(t), bits(ot)), bld
+            osc.close()
+
+
 def test_device_builders_are_deterministic_f1():
     """every choice in the device builders is a sort, a scan or a strict total order (ties between equal Morton
     codes / equal merge costs are broken by position), so two builds of the same scene give the same tree"""
@@ -640,3 +673,16 @@ def test_random_soups_production_kernels_bit_exact(kind):
         rids, rtt = p.cpu.trace(oo, dd)
         assert np.array_equal(ids, rids) and np.array_equal(bits(tt), bits(rtt)), (kind, n)
         p.close()
+        # the same soup through the quality tree the GPU builds (PLOC): the reference's traversal over the exported
+        # tree must agree bit for bit, frames included (duplicates and degenerate boxes stress the clustering)
+        with va.Scene(pos, nrm, uv, leaf_size=leaf, builder=va._lib.VMX_BVH_PLOC) as g:
+            tree = g.bvh()
+            assert sorted(tree["prim_order"].tolist()) == list(range(n))
+            osc = O.OracleScene(pos, nrm, uv, leaf_size=leaf, tree=tree)
+            tri, t = g.trace(o, d)
+            otri, ot = osc.trace(o, d)
+            assert np.array_equal(tri, otri) and np.array_equal(bits(t), bits(ot)), (kind, n, "ploc")
+            img, _ = g.render(cam, va.make_opts(seed=5, early_stop=False, pipeline=4))
+            oimg, _ = osc.render(cam, va.make_opts(seed=5, early_stop=False))
+            assert np.array_equal(bits(img), bits(oimg)), (kind, n, "ploc frame")
+            osc.close()
