@@ -2281,7 +2281,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                 // all 64 lanes at the same inner node: the assembly loop takes the wave down the tree while that
                 // holds (uniform_descent), the general step goes on from where it stopped
                 const unsigned long long trav = __builtin_amdgcn_ballot_w64(cur != kIdle);
-                if (trav != 0) {
+                if (trav == 0) break;  // every ray of the wave is done: on to the refill (these waves refill all 64 lanes at once)
+                {
                     const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)__ffsll((long long)trav) - 1);
                     if (c0 < kPop && __builtin_amdgcn_ballot_w64(cur != kIdle && (cur != c0 || sp >= lds_entries)) == 0)
                     {
