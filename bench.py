@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (frames travel through host memory)")
     ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (rehearsal)")
+    ap.add_argument("--reorder", type=lambda v: int(v, 0), default=0,
+                    help="experiment: bounce reordering key (vmx_opts.reserved[5], tools/sort_probe.py); 0 = library default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,7 +112,7 @@ def main():
 
     def step(early_stop=False, counters=False):
         opts = va.make_opts(seed=args.seed, early_stop=early_stop, sampling=va.VMX_SAMPLING_PARITY, rank=rank,
-                            world=world, stripe_rows=stripe, collect_counters=counters)
+                            world=world, stripe_rows=stripe, collect_counters=counters, reorder=args.reorder)
         st = sc.render_device(cam, opts, local.data_ptr(), stream)
         st["kernels"] = sc.timings()  # per-kernel hipEvent durations of this frame (on the render stream)
         src = local if args.backend == "nccl" or world == 1 else local.cpu()

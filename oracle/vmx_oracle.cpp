@@ -524,6 +524,59 @@ inline void texture_sample(const orc_scene &sc, V2 uv, V4 *out) {
     texture_sample_of(sc.tex.data(), sc.tex_w, sc.tex_h, sc.tex_c, uv, out);
 }
 
+/* ---- cos / sin of a float argument -------------------------------------------------------------------
+ * pathtracer.cpp:155,162 call the UNQUALIFIED cos(r1) / sin(r1) with `float r1`.  Which function that names
+ * depends on whether <cmath>'s float overloads are visible in the global namespace — the same question as the
+ * unqualified abs(float) of integrators.cpp:170 (render_bruteforce below).  One premise, one default: the
+ * overloads are visible, so abs -> std::abs(float) and cos/sin -> cosf/sinf; the other reading (C's
+ * `double cos(double)` on the widened argument, abs(int)) is selected by VMX_SAMPLING_LIBM_DOUBLE /
+ * VMX_BF_ABS_INT.  sqrt(float) and fabs(float) at :157,160,162 give the same value under both readings
+ * (sqrt is correctly rounded: narrowing the double root of a float is the float root).
+ *
+ * cosf / sinf are third-party arithmetic: the reference links the platform's libm (glibc on the Linux it is
+ * built for, .travis.yml).  Restated here is glibc's algorithm since 2.28 (sysdeps/ieee754/flt-32/s_sinf.c,
+ * s_cosf.c, sincosf.h = ARM optimized-routines' sinf/cosf): argument < pi/4: polynomial in double; else
+ * n = round(x * 2/pi) via the 2^24-scaled product, x - n * (pi/2) in double, sign and polynomial by quadrant.
+ * Only the range r1 can take, [0, float(2 pi)], is restated (the |x| >= 120 path is not).  Pinned:
+ * orc_trig_compare_libm() compares every float of that range with THIS image's libm (glibc 2.35) — 0 of
+ * 1,086,918,620 differ for both functions (tests/test_oracle.py); the kernels run the same operations. */
+struct SinCosTab {
+    double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3;
+};
+const SinCosTab kSinCos[2] = {
+    {0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+     -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+    {0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+     0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+inline float sincosf_poly(double x, double x2, const SinCosTab &p, int n) {
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, s1 = p.s2 + x2 * p.s3, x7 = x3 * x2, s = x + x3 * p.s1;
+        return (float)(s + x7 * s1);
+    }
+    const double x4 = x2 * x2, c2 = p.c3 + x2 * p.c4, c1 = p.c0 + x2 * p.c1, x6 = x4 * x2, c = c1 + x4 * p.c2;
+    return (float)(c + x6 * c2);
+}
+inline uint32_t abstop12(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return (u >> 20) & 0x7ffu;
+}
+/* which = 0: sinf, 1: cosf; 0 <= y <= 2 pi */
+inline float libm_sincosf(float y, int which) {
+    double x = y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
+        if (abstop12(y) < abstop12(0x1p-12f)) return which ? 1.0f : y;
+        return sincosf_poly(x, x * x, kSinCos[0], which);
+    }
+    const double r = x * kSinCos[0].hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - n * kSinCos[0].hpi;
+    static const double sign[4] = {1.0, -1.0, -1.0, 1.0};
+    return sincosf_poly(x * sign[n & 3], x * x, kSinCos[(n >> 1) & 1], n ^ which);
+}
+inline float restated_sinf(float y) { return libm_sincosf(y, 0); }
+inline float restated_cosf(float y) { return libm_sincosf(y, 1); }
+
 /* Radiance, pathtracer.cpp:21-198.  No texture is bound in any configuration
  * (pathtracer.cpp:63-66 not taken), so sampleColour is (1,1,1,1) (:75-79) unless a
  * texture was bound with orc_scene_bind_texture (then :63-66, VermiTexture::Sample). */
@@ -533,7 +586,8 @@ V4 radiance(const orc_scene &sc, V3 rStart, V3 rDir, Rng &rng, uint32_t sampling
     V4 accumColour = {0, 0, 0, -100};
     V4 accumRadiance = {1, 1, 1, 1};
     short depth = 0;
-    const double r2scale = (sampling == VMX_SAMPLING_CORRECTED) ? 1.0 : 10.0;
+    const double r2scale = ((sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED) ? 1.0 : 10.0;
+    const bool libm_double = (sampling & VMX_SAMPLING_LIBM_DOUBLE) != 0;
     while (1) {
         bool is_ray = finite3(rDir); /* NaN directions are not rays */
         if (st) {
@@ -570,8 +624,10 @@ V4 radiance(const orc_scene &sc, V3 rStart, V3 rDir, Rng &rng, uint32_t sampling
             V3 w = dot(n, rDir) < 0.f ? n : n * -1.f;
             V3 u = normalize(cross(std::fabs(w.x) > .1 ? v3(0, 1, 0) : v3(1, 0, 0), w));
             V3 v = cross(w, u);
-            V3 dd = normalize(u * (float)std::cos((double)r1) * r2s + v * (float)std::sin((double)r1) * r2s +
-                              w * (float)std::sqrt(1 - r2));
+            /* float(cos(r1)), float(sin(r1)) with float r1 (:162): cosf/sinf, or C's double functions (see above) */
+            const float cs = libm_double ? (float)std::cos((double)r1) : restated_cosf(r1);
+            const float sn = libm_double ? (float)std::sin((double)r1) : restated_sinf(r1);
+            V3 dd = normalize(u * cs * r2s + v * sn * r2s + w * (float)std::sqrt(1 - r2));
             rStart = c.location - rDir * 0.001f;
             next_dir = dd;
         } else { /* :166-196, nearest hit is a sphere and the BVH hit nothing */
@@ -1059,6 +1115,34 @@ void orc_stream(uint64_t seed, uint32_t pixel, uint32_t k, uint32_t n, uint64_t 
 uint64_t orc_splitmix64(uint64_t *state) { return splitmix64(*state); }
 
 /* Camera::saveFrame conversion loop, camera.cpp:159-163 (RGBAZ) */
+/* the restated cosf / sinf (see libm_sincosf) for explicit arguments in [0, 2 pi] */
+void orc_trig(const float *x, uint32_t n, float *cos_out, float *sin_out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        cos_out[i] = restated_cosf(x[i]);
+        sin_out[i] = restated_sinf(x[i]);
+    }
+}
+/* how many floats with bit patterns in [lo_bits, hi_bits] (non-negative floats) the restatement and the HOST's
+ * libm disagree on: the pin of the restatement against the platform library it restates */
+void orc_trig_compare_libm(uint32_t lo_bits, uint32_t hi_bits, uint64_t *cos_diff, uint64_t *sin_diff) {
+    uint64_t dc = 0, ds = 0;
+    float (*volatile host_cosf)(float) = cosf; /* through pointers: the compiler must not fold the libm calls */
+    float (*volatile host_sinf)(float) = sinf;
+    float (*const hc)(float) = host_cosf;
+    float (*const hs)(float) = host_sinf;
+#pragma omp parallel for reduction(+ : dc, ds) schedule(static)
+    for (uint64_t b = lo_bits; b <= (uint64_t)hi_bits; ++b) {
+        const uint32_t bb = (uint32_t)b;
+        float x;
+        std::memcpy(&x, &bb, 4);
+        const float c1 = hc(x), c2 = restated_cosf(x), s1 = hs(x), s2 = restated_sinf(x);
+        if (std::memcmp(&c1, &c2, 4)) dc++;
+        if (std::memcmp(&s1, &s2, 4)) ds++;
+    }
+    *cos_diff = dc;
+    *sin_diff = ds;
+}
+
 void orc_quantize(const float *frame, uint64_t npix, unsigned char *rgba8, float *depth) {
     for (uint64_t p = 0; p < npix; ++p) {
         rgba8[p * 4 + 0] = static_cast<unsigned char>(std::floor(frame[p * 5 + 0] * 255));

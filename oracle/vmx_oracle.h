@@ -75,6 +75,10 @@ void orc_render(const orc_scene *, const vmx_camera *cam, const vmx_opts *opts, 
 void orc_render_bruteforce(const orc_scene *, const vmx_camera *cam, const vmx_opts *opts, uint32_t flags,
                            int threads, float *out_rgbaz, vmx_stats *stats);
 int orc_max_threads(void);
+/* cosf / sinf as pathtracer.cpp:162 gets them under the default reading (glibc's algorithm restated), and the
+ * count of floats in a bit-pattern range on which that restatement differs from the host's libm */
+void orc_trig(const float *x, uint32_t n, float *cos_out, float *sin_out);
+void orc_trig_compare_libm(uint32_t lo_bits, uint32_t hi_bits, uint64_t *cos_diff, uint64_t *sin_diff);
 /* Camera::saveFrame conversion (camera.cpp:159-163) */
 void orc_quantize(const float *frame, uint64_t npix, unsigned char *rgba8, float *depth);
 

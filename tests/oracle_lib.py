@@ -64,6 +64,8 @@ def lib(fast=False):
                                         C.POINTER(L.Stats)]
     l.orc_max_threads.restype = C.c_int
     l.orc_quantize.argtypes = [P, C.c_uint64, P, P]
+    l.orc_trig.argtypes = [P, C.c_uint32, P, P]
+    l.orc_trig_compare_libm.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _libs[name] = l
     return l
 
@@ -209,3 +211,18 @@ def quantize(frame):
     depth = np.empty(n, np.float32)
     lib().orc_quantize(frame.ctypes.data, n, rgba.ctypes.data, depth.ctypes.data)
     return rgba, depth
+
+
+def trig(x):
+    """restated cosf / sinf of the default reading of pathtracer.cpp:162 (oracle: libm_sincosf)"""
+    x = np.ascontiguousarray(x, np.float32)
+    cs, sn = np.empty_like(x), np.empty_like(x)
+    lib().orc_trig(x.ctypes.data, x.size, cs.ctypes.data, sn.ctypes.data)
+    return cs, sn
+
+
+def trig_compare_libm(lo_bits, hi_bits):
+    """(cosf, sinf) counts of floats in the bit-pattern range where the restatement differs from the host libm"""
+    dc, ds = C.c_uint64(0), C.c_uint64(0)
+    lib().orc_trig_compare_libm(int(lo_bits), int(hi_bits), C.byref(dc), C.byref(ds))
+    return dc.value, ds.value

@@ -97,6 +97,23 @@ def test_primary_hit_triangle_ids_bit_exact(pair):
         assert (tri >= 0).mean() > 0.1
 
 
+def test_device_cosf_sinf_bit_exact():
+    """cos(r1) / sin(r1) with float r1 (pathtracer.cpp:162) under the default reading: the kernels' glibc-algorithm
+    cosf / sinf (vmx_trig) against the oracle's restatement, which tests/test_oracle.py pins against the host libm on
+    every float of [0, 2 pi]: 8 M arguments spread over the range, every exponent, and the range's ends."""
+    r = np.random.RandomState(11)
+    top = int(np.float32(2 * np.pi).view(np.uint32))
+    x = np.concatenate([
+        (np.float32(2 * np.pi) * r.random_sample(4_000_000)).astype(np.float32),          # as r1 is distributed
+        r.randint(0, top + 1, size=4_000_000).astype(np.uint32).view(np.float32),          # uniform over bit patterns
+        np.array([0, 1, 0x00800000, 0x39800000 - 1, 0x39800000, 0x3F490FDA, 0x3F490FDB, 0x3F490FDC, top - 1, top],
+                 np.uint32).view(np.float32)])
+    cs, sn = np.empty_like(x), np.empty_like(x)
+    va._lib.check(va._lib.lib().vmx_trig(x.ctypes.data, x.size, cs.ctypes.data, sn.ctypes.data, 0))
+    rcs, rsn = O.trig(x)
+    assert np.array_equal(bits(cs), bits(rcs)) and np.array_equal(bits(sn), bits(rsn))
+
+
 # Which kernels a call runs (vmx_api.cpp: render_impl, run_ids):
 #   {}                                  default routing — a pass of < 4 M paths goes to the fused k_paths kernel,
 #                                       bounce generations of <= 16 M live paths to the fused tail (k_paths<2>)
@@ -110,7 +127,7 @@ FORM_IDS = ["default", "split", "split-notail"]
 
 
 @pytest.mark.parametrize("form", PRODUCTION_FORMS, ids=FORM_IDS)
-@pytest.mark.parametrize("sampling", [0, 1])
+@pytest.mark.parametrize("sampling", [0, 1, 0x100, 0x101])  # 0x100: VMX_SAMPLING_LIBM_DOUBLE, the other reading of cos/sin(float)
 def test_radiance_paths_bit_exact(pair, sampling, form):
     """vmx_radiance starts from explicit rays, so its first generation already is a *bounce* generation for
     the kernels: with tail_threshold=1 every generation runs k_trace_w<1> (bvh.cpp:47-145) + k_shade<1>,
@@ -135,11 +152,11 @@ def test_radiance_paths_bit_exact(pair, sampling, form):
 
 
 @pytest.mark.parametrize("form", PRODUCTION_FORMS, ids=FORM_IDS)
-@pytest.mark.parametrize("early_stop,sampling", [(1, 0), (0, 0), (1, 1), (0, 1)])
+@pytest.mark.parametrize("early_stop,sampling", [(1, 0), (0, 0), (1, 1), (0, 1), (0, 0x100), (1, 0x101)])
 def test_frame_bit_exact(pair, early_stop, sampling, form):
     c = pair.camf()
     W, H, spp = (160, 96, 16) if pair.name in ("bunny70k", "sponza260k") else (128, 128, 16)
-    if sampling == 1 and pair.name == "sponza260k":
+    if (sampling & 0xFF) == 1 and pair.name == "sponza260k":
         W, H = 96, 64  # the oracle needs ~25 rays per sample here
     cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
     opts = va.make_opts(seed=9, early_stop=bool(early_stop), sampling=sampling, **form)

@@ -39,7 +39,7 @@ def test_full_size_frame_invariants(sponza):
     # scheduling must not change a single bit
     for kw in (dict(samples_per_batch=3), dict(pipeline=1), dict(pipeline=2), dict(pipeline=3), dict(pipeline=4), dict(tail_threshold=1),
                dict(max_paths=1 << 20), dict(refill_min=1, shade_min=1), dict(refill_min=64, shade_min=64),
-               dict(refill_min=5, shade_min=40), dict(leaf_min=0xFFFFFFFF), dict(leaf_min=1, lds_entries=3),
+               dict(refill_min=5, shade_min=40), dict(reorder=0x35, tail_threshold=1), dict(reorder=0x108044, tail_threshold=4096, lds_entries=3),
                dict(lds_entries=40), dict(lds_entries=1), dict(collect_counters=True)):
         b, sb = sponza.render(cam, va.make_opts(seed=1, early_stop=False, **kw))
         assert np.array_equal(bits(a), bits(b)), kw

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, vermilion_amd as va
 from vermilion_amd import scenes
 pos, nrm, uv = scenes.sponza260k(); c = scenes.sponza_camera()

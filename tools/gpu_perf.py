@@ -31,7 +31,7 @@ def main():
         if os.environ.get("SHADE"): kw["shade_min"] = int(os.environ["SHADE"])
         if os.environ.get("TAIL"): kw["tail_threshold"] = int(os.environ["TAIL"])
         if os.environ.get("MAXP"): kw["max_paths"] = int(os.environ["MAXP"])
-        if os.environ.get("LEAF"): kw["leaf_min"] = int(os.environ["LEAF"])
+        if os.environ.get("REORDER"): kw["reorder"] = int(os.environ["REORDER"], 0)
         if os.environ.get("LDSE"): kw["lds_entries"] = int(os.environ["LDSE"])
         for r in range(reps):
             opts = va.make_opts(seed=1, early_stop=bool(es), sampling=sampling, **kw)

@@ -20,6 +20,7 @@ VMX_ERR_NOMEM = 5
 VMX_SPHERE_EMIT = 1
 VMX_SAMPLING_PARITY = 0
 VMX_SAMPLING_CORRECTED = 1
+VMX_SAMPLING_LIBM_DOUBLE = 0x100
 VMX_BVH_REFERENCE = 0
 VMX_BVH_SAH = 1
 VMX_BVH_LBVH = 2
@@ -162,6 +163,7 @@ SYMBOLS = {
     "vmx_raycast": (C.c_int, [_P, _P, _P, C.c_uint32, _P]),
     "vmx_primary_ids": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), C.c_uint32, _P, _P]),
     "vmx_radiance": (C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(Opts), _P, C.POINTER(Stats)]),
+    "vmx_trig": (C.c_int, [_P, C.c_uint32, _P, _P, C.c_int]),
     "vmx_local_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "vmx_render": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),
     "vmx_render_device": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, _P, C.POINTER(Stats)]),

@@ -114,6 +114,8 @@ struct Workspace {
     DevBuf<unsigned char> overflow_stack;  // k_paths: stack levels beyond the LDS part
     DevBuf<unsigned char> rayA, state, hit, thr;  // split wavefront: per-path state
     DevBuf<unsigned int> ids[2], id_counts;             // split wavefront: live path ids
+    DevBuf<unsigned int> sort_keys[2], ids_sorted;      // bounce reordering (path_sort.hip)
+    DevBuf<unsigned char> sort_tmp;
     DevBuf<unsigned char> cam_inner, cam_tris;          // per-frame camera-relative scene tables
     DevBuf<unsigned char> rad;          // float4 per path of a pass
     DevBuf<unsigned char> accum;        // float4 per local pixel
@@ -127,6 +129,7 @@ struct Workspace {
         queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), heads.release(), overflow_stack.release();
         rayA.release(), state.release(), hit.release(), thr.release();
         ids[0].release(), ids[1].release(), id_counts.release(), cam_inner.release(), cam_tris.release();
+        sort_keys[0].release(), sort_keys[1].release(), ids_sorted.release(), sort_tmp.release();
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
     }
@@ -156,6 +159,7 @@ struct vmx_scene {
     std::mutex mu;
     Workspace ws;
     uint32_t block = 256;
+    float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {1, 1, 1};  // vertex bounds (origin cells of the bounce reordering)
     vmx_timings timings{};  // per-kernel durations of the last render on this scene
 };
 
@@ -204,7 +208,8 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
     if (spp < 4)
         return fail(VMX_ERR_INVALID,
                     "rays_per_pixel < 4 renders no sample (uSamplesPerPixel/4 == 0, pathtracer.cpp:247)");
-    if (o.sampling > VMX_SAMPLING_CORRECTED) return fail(VMX_ERR_INVALID, "unknown sampling mode");
+    if ((o.sampling & VMX_SAMPLING_MODE_MASK) > VMX_SAMPLING_CORRECTED || (o.sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE)))
+        return fail(VMX_ERR_INVALID, "unknown sampling mode");
     const float rx = (float)(-cam.rotation_deg[0] * 3.1415926535 / 180);
     const float ry = (float)(-cam.rotation_deg[1] * 3.1415926535 / 180);
     const float rz = (float)(cam.rotation_deg[2] * 3.1415926535 / 180);
@@ -221,7 +226,8 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
     fr.spp = spp, fr.quarter = spp / 4, fr.kmax = 4 * (spp / 4);
     fr.nmin = (uint32_t)std::floor(std::sqrt((double)spp));
     fr.early_stop = o.early_stop ? 1u : 0u;
-    fr.r2scale = o.sampling == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
+    fr.r2scale = (o.sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
+    fr.libm_double = (o.sampling & VMX_SAMPLING_LIBM_DOUBLE) ? 1u : 0u;
     fr.world = o.world <= 1 ? 1u : o.world;
     fr.rank = o.world <= 1 ? 0u : o.rank;
     fr.stripe_rows = o.stripe_rows ? o.stripe_rows : 16u;
@@ -272,7 +278,7 @@ struct TimedLaunch {
 
 // reads the 16 sub-queue tails; returns total and the largest
 int read_counts(vmx_scene *sc, unsigned int *d_counts, hipStream_t s, uint64_t &total, uint32_t &largest,
-                uint32_t sub_capacity = 0xffffffffu) {
+                uint32_t sub_capacity = 0xffffffffu, uint32_t *per_queue = nullptr) {
     unsigned int h[kSubQueues * 32];
     HIP_TRY(hipMemcpyAsync(h, d_counts, sizeof(h), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -281,12 +287,13 @@ int read_counts(vmx_scene *sc, unsigned int *d_counts, hipStream_t s, uint64_t &
         const uint32_t c = std::min(h[q * 32], sub_capacity);  // an overflowing append leaves the tail high
         total += c;
         largest = std::max(largest, c);
+        if (per_queue) per_queue[q] = c;
     }
     (void)sc;
     return VMX_OK;
 }
 
-int run_queue(vmx_scene *sc, float r2scale, QueueDev q[2], int cur, void *rad, DevCounters *ctr, bool count,
+int run_queue(vmx_scene *sc, const FrameDev &fr, QueueDev q[2], int cur, void *rad, DevCounters *ctr, bool count,
               uint32_t tail_threshold, hipStream_t s, std::vector<TimedLaunch> &timed, uint64_t &launches,
               int bounce_blocks) {
     Workspace &ws = sc->ws;
@@ -303,7 +310,7 @@ int run_queue(vmx_scene *sc, float r2scale, QueueDev q[2], int cur, void *rad, D
         TimedLaunch tl{ws.events.get(), ws.events.get(), 1, VMX_K_OTHER};
         if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(tl.a, s));
-        LAUNCH_TRY(launch_bounce(sc->dev, r2scale, q[cur], max_chunks, q[cur ^ 1], rad, ctr, count, tail, false,
+        LAUNCH_TRY(launch_bounce(sc->dev, fr.r2scale, fr.libm_double, q[cur], max_chunks, q[cur ^ 1], rad, ctr, count, tail, false,
                                  cfg, s));
         HIP_TRY(hipEventRecord(tl.b, s));
         timed.push_back(tl);
@@ -317,6 +324,7 @@ int run_queue(vmx_scene *sc, float r2scale, QueueDev q[2], int cur, void *rad, D
 struct Tuning {
     uint32_t refill_min, refill_primary, shade_min, leaf_min, tail_threshold;
     uint32_t lds_entries, lds_primary, lds_bounce;  // LDS stack levels: fused kernels, camera-ray trace, bounce trace
+    uint32_t sort_mode;  // bounce reordering: obits | dbits << 4 | dir_major << 8 | chunk_log2 << 12 | shade_sorted << 20
 };
 
 Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
@@ -328,7 +336,8 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.refill_min = o->reserved[3] ? o->reserved[3] : 8u;
     tn.refill_primary = o->reserved[3] ? o->reserved[3] : 64u;
     tn.shade_min = o->reserved[4] ? o->reserved[4] : 16u;
-    tn.leaf_min = o->reserved[5] ? o->reserved[5] : 0xFFFFFFFFu;  // k_paths only: triangle-step vote (default: majority)
+    tn.leaf_min = 0xFFFFFFFFu;
+    tn.sort_mode = o->reserved[5];
     // LDS stack levels per lane (+1 scratch level), 512 B per level and wave.  Measured on the Sponza
     // stand-in: camera rays rarely go deep and gain from the 8th wave per SIMD that 8 levels leave
     // room for (52.6 -> 50.6 ms); the bounce kernel, once its record fetch is quad-cooperative, prefers
@@ -410,7 +419,8 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
     for (;;) {
         uint64_t total;
         uint32_t largest;
-        int rc = read_counts(sc, q[cur].counts, s, total, largest, q[cur].sub_capacity);
+        uint32_t per_queue[kSubQueues];
+        int rc = read_counts(sc, q[cur].counts, s, total, largest, q[cur].sub_capacity, per_queue);
         if (rc) return rc;
         if (total == 0) break;
         const bool tail = total <= tn.tail_threshold;
@@ -420,6 +430,34 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
         wk.nsrc = kSubQueues;
         wk.refill_min = tn.refill_min, wk.shade_min = tn.shade_min;
         wk.qids = q[cur];
+        IdQueue q_shade = q[cur];
+        if (!tail && tn.sort_mode) {
+            // reorder the live ids by (origin cell, direction cell) of their next rays (path_sort.hip)
+            const size_t qsize = (size_t)q[cur].sub_capacity * kSubQueues;
+            const size_t tmp_bytes = path_sort_tmp_bytes(largest);
+            if (ws.sort_keys[0].ensure(qsize) || ws.sort_keys[1].ensure(qsize) || ws.ids_sorted.ensure(qsize) ||
+                ws.sort_tmp.ensure(tmp_bytes))
+                return fail(VMX_ERR_NOMEM, "hipMalloc failed for the path sort");
+            SortKeyCfg kc;
+            for (int a = 0; a < 3; ++a) {
+                kc.lo[a] = sc->bounds_lo[a];
+                const float ext = sc->bounds_hi[a] - sc->bounds_lo[a];
+                kc.inv[a] = ext > 0.f ? 1.0f / ext : 0.f;
+            }
+            kc.obits = tn.sort_mode & 15u, kc.dbits = (tn.sort_mode >> 4) & 15u;
+            kc.dir_major = (tn.sort_mode >> 8) & 1u, kc.chunk_log2 = (tn.sort_mode >> 12) & 31u;
+            if (kc.obits > 10 || kc.dbits > 8 || 3 * kc.obits + 2 * kc.dbits > 32)
+                return fail(VMX_ERR_INVALID, "bounce reordering: key wider than 32 bits");
+            TimedLaunch tso{ws.events.get(), ws.events.get(), -1, VMX_K_OTHER};
+            if (!tso.a || !tso.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(tso.a, s));
+            LAUNCH_TRY(path_sort_ids(q[cur], per_queue, pa.state, kc, ws.sort_keys[0].p, ws.sort_keys[1].p, ws.ids_sorted.p,
+                                     ws.sort_tmp.p, tmp_bytes, s));
+            HIP_TRY(hipEventRecord(tso.b, s));
+            timed.push_back(tso);
+            wk.qids.ids = ws.ids_sorted.p;
+            if ((tn.sort_mode >> 20) & 1u) q_shade.ids = ws.ids_sorted.p;
+        }
         const uint32_t entries = tail ? tn.lds_entries : tn.lds_bounce;
         LaunchCfg cfg = paths_cfg(sc, entries, total, tail ? tail_blocks : trace_blocks);
         rc = bind_stack(sc, tn, entries, cfg.grid, total, wk);
@@ -442,6 +480,7 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
         TimedLaunch ts{ws.events.get(), ws.events.get(), 2, VMX_K_SHADE_BOUNCE};
         if (!ts.a || !ts.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(ts.a, s));
+        wk.qids = q_shade;
         LAUNCH_TRY(launch_shade(sc->dev, fr, wk, nopx, pa, q[cur ^ 1], (largest + 255) / 256, ctr, true, s));
         HIP_TRY(hipEventRecord(ts.b, s));
         timed.push_back(ts);
@@ -739,7 +778,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             rc = run_ids(sc, fr, pa, qi, 0, ws.counters.p, count, tn, s, timed, launches, tbb, rb);
             if (rc) return rc;
         } else if (!mega) {
-            rc = run_queue(sc, fr.r2scale, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed, launches,
+            rc = run_queue(sc, fr, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed, launches,
                            bb);
             if (rc) return rc;
         }
@@ -893,6 +932,12 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
         sc->spheres.assign(spheres, spheres + nspheres);
     else
         sc->spheres.assign(kReferenceSpheres, kReferenceSpheres + 8);
+    for (int a = 0; a < 3; ++a) sc->bounds_lo[a] = sc->bounds_hi[a] = pos[a];
+    for (size_t v = 0; v < (size_t)ntris * 3; ++v)
+        for (int a = 0; a < 3; ++a) {
+            sc->bounds_lo[a] = std::min(sc->bounds_lo[a], pos[v * 3 + a]);
+            sc->bounds_hi[a] = std::max(sc->bounds_hi[a], pos[v * 3 + a]);
+        }
     const int rc = scene_upload(sc);
     if (rc) {
         const std::string keep = g_err;
@@ -1073,7 +1118,9 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
                  float *out, vmx_stats *stats) {
     vmx_scene *sc = const_cast<vmx_scene *>(csc);
     if (!sc || !origin || !dir || !opts || !out) return fail(VMX_ERR_INVALID, "NULL argument");
-    if (opts->sampling > VMX_SAMPLING_CORRECTED) return fail(VMX_ERR_INVALID, "unknown sampling mode");
+    if ((opts->sampling & VMX_SAMPLING_MODE_MASK) > VMX_SAMPLING_CORRECTED ||
+        (opts->sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE)))
+        return fail(VMX_ERR_INVALID, "unknown sampling mode");
     if (opts->reserved[0] > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
     if (sc->dev.tex && opts->reserved[0] >= 2 && opts->reserved[0] <= 3)
         return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
@@ -1089,7 +1136,8 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     const Tuning tn = make_tuning(sc, opts);
     FrameDev fr;
     std::memset(&fr, 0, sizeof(fr));
-    fr.r2scale = opts->sampling == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
+    fr.r2scale = (opts->sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
+    fr.libm_double = (opts->sampling & VMX_SAMPLING_LIBM_DOUBLE) ? 1u : 0u;
     QueueDev q[2];
     PathArrays pa{};
     IdQueue qi[2];
@@ -1125,7 +1173,7 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
             HIP_TRY(hipMemsetAsync(q[0].counts, 0, kSubQueues * 32 * 4, s));
             LAUNCH_TRY(launch_radiance_init(d_o.p, d_d.p, n, opts->seed, q[0], s));
             launches += 2;
-            r = run_queue(sc, fr.r2scale, q, 0, ws.rad.p, ws.counters.p, count, tn.tail_threshold, s, timed, launches, bb);
+            r = run_queue(sc, fr, q, 0, ws.rad.p, ws.counters.p, count, tn.tail_threshold, s, timed, launches, bb);
         } else {
             HIP_TRY(hipMemsetAsync(qi[0].counts, 0, kSubQueues * 32 * 4, s));
             LAUNCH_TRY(launch_radiance_init_ids(d_o.p, d_d.p, n, opts->seed, pa, qi[0], s));
@@ -1141,6 +1189,23 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     d_o.release(), d_d.release();
     if (rc == VMX_OK && stats) stats->samples = n;
     return rc;
+}
+
+int vmx_trig(const float *x, uint32_t n, float *cos_out, float *sin_out, int device) {
+    if (!x || !cos_out || !sin_out) return fail(VMX_ERR_INVALID, "NULL argument");
+    if (n == 0) return VMX_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(VMX_ERR_NO_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<float> d_x, d_c, d_s;
+    if (d_x.ensure(n) || d_c.ensure(n) || d_s.ensure(n)) return fail(VMX_ERR_NOMEM, "hipMalloc failed");
+    hipError_t e = hipMemcpy(d_x.p, x, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = (hipError_t)launch_trig(d_x.p, n, d_c.p, d_s.p, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(cos_out, d_c.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(sin_out, d_s.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+    d_x.release(), d_c.release(), d_s.release();
+    if (e != hipSuccess) return fail(VMX_ERR_HIP, std::string("vmx_trig: ") + hipGetErrorString(e));
+    return VMX_OK;
 }
 
 int vmx_local_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world, uint32_t *rows) {
@@ -1436,6 +1501,8 @@ int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32
             sc->ntris = first->ntris, sc->leaf_size = first->leaf_size;
             sc->bvh = first->bvh;
             sc->spheres = first->spheres;
+            std::memcpy(sc->bounds_lo, first->bounds_lo, sizeof(sc->bounds_lo));
+            std::memcpy(sc->bounds_hi, first->bounds_hi, sizeof(sc->bounds_hi));
             rc = scene_upload(sc);
             if (rc) {
                 const std::string keep = g_err;

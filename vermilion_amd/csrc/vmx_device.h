@@ -101,6 +101,7 @@ struct FrameDev {
     uint32_t lead;                // per pass: > 0 in the first early-stop pass — paths j < lead are samples j,
                                   // paths j >= lead the first samples of the following strata (sample_index)
     float r2scale;                // 10 (parity) or 1 (corrected)
+    uint32_t libm_double;         // VMX_SAMPLING_LIBM_DOUBLE: cos/sin(float r1) of pathtracer.cpp:162 as C's double functions
     uint32_t local_rows;          // rows owned by this rank
     uint32_t stripe_rows, rank, world;
     uint64_t seed;

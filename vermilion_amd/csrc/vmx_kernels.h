@@ -82,6 +82,8 @@ int launch_raycast(const SceneDev &sc, const float *o, const float *d, uint32_t 
 int launch_primary_ids(const SceneDev &sc, const FrameDev &fr, uint32_t k, int32_t *tri_id, float *t,
                        LaunchCfg cfg, void *stream);
 
+int launch_trig(const float *x, uint32_t n, float *cs, float *sn, void *stream);
+
 // ---- render pipeline -----------------------------------------------------------
 int launch_init_pixels(PixelStateDev px, uint32_t npix, void *stream);
 int launch_zero_u32(unsigned int *p, uint32_t n, void *stream);
@@ -94,7 +96,7 @@ int launch_primary(const SceneDev &sc, const FrameDev &fr, const unsigned int *a
 int launch_radiance_init(const float *o, const float *d, uint32_t n, uint64_t seed, QueueDev qout,
                          void *stream);
 // one bounce (or, loop_to_end, all remaining bounces) of every queued path
-int launch_bounce(const SceneDev &sc, float r2scale, QueueDev qin, uint32_t max_chunks, QueueDev qout,
+int launch_bounce(const SceneDev &sc, float r2scale, uint32_t libm_double, QueueDev qin, uint32_t max_chunks, QueueDev qout,
                   void *rad, DevCounters *counters, bool count, bool loop_to_end, bool first_step,
                   LaunchCfg cfg, void *stream);
 // per-pixel accumulation in sample order, early-stop rule, pixel write, next active list
@@ -131,6 +133,21 @@ int launch_bruteforce_long(const SceneDev &sc, const FrameDev &fr, uint32_t flag
 int launch_quantize(const float *frame, uint64_t npix, void *rgba8, float *depth, void *stream);
 int launch_assemble(const float *gathered, uint64_t rank_stride_floats, uint32_t width, uint32_t height,
                     uint32_t stripe_rows, uint32_t world, float *frame, void *stream);
+
+// ---- live-path reordering between bounce generations (path_sort.hip) -----------------------------
+struct SortKeyCfg {
+    float lo[3], inv[3];  // scene bounds: cell = (o - lo) * inv in [0,1)
+    uint32_t obits;       // bits per axis of the origin cell (Morton-interleaved), 0 = no origin part
+    uint32_t dbits;       // bits per axis of the octahedral direction cell, 0 = no direction part
+    uint32_t dir_major;   // 1: direction cell in the high bits
+    uint32_t chunk_log2;  // > 0: key = (queue position >> chunk_log2, direction cell): direction order inside chunks
+};
+size_t path_sort_tmp_bytes(uint32_t max_n);
+// sorts every sub-queue of `q` (h_counts[kSubQueues] entries each) by the key of its paths' next rays into ids_out
+// (same sub-queue layout); keys_a / keys_b: scratch of the queue's size
+int path_sort_ids(const IdQueue &q, const uint32_t *h_counts, const void *state, const SortKeyCfg &cfg,
+                  unsigned int *keys_a, unsigned int *keys_b, unsigned int *ids_out, void *tmp, size_t tmp_bytes,
+                  void *stream);
 
 // occupancy helpers (host): blocks per CU for the trace-heavy kernels at this LDS size
 int query_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *primary_blocks,

@@ -539,6 +539,47 @@ __device__ __forceinline__ float4 tex_sample(const SceneDev &sc, float u, float 
     return tex_sample_of(sc.tex, sc.tex_w, sc.tex_h, sc.tex_c, u, v);
 }
 
+// cosf / sinf of r1 in [0, 2 pi] as glibc computes them (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h —
+// ARM optimized-routines): the default reading of the unqualified cos(r1) / sin(r1) with float r1 at
+// pathtracer.cpp:155,162 (include/vermilion_hip.h: VMX_SAMPLING_LIBM_DOUBLE).  Double-precision operations in
+// glibc's order, no contraction; the test suite's CPU restatement of the same algorithm is pinned against the
+// host libm on every float of the range, and vmx_trig() exposes this function for the comparison.
+// which = 0: sinf, 1: cosf.
+__device__ __forceinline__ float libm_sincosf_poly(double x, double x2, bool neg, int n) {
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13, x7 = x3 * x2,
+                     s = x + x3 * -0x1.555545995a603p-3;
+        return (float)(s + x7 * s1);
+    }
+    // the second table is the first with the cosine coefficients negated
+    const double c0 = neg ? -0x1p0 : 0x1p0, c1 = neg ? 0x1.ffffffd0c621cp-2 : -0x1.ffffffd0c621cp-2,
+                 c2 = neg ? -0x1.55553e1068f19p-5 : 0x1.55553e1068f19p-5,
+                 c3 = neg ? 0x1.6c087e89a359dp-10 : -0x1.6c087e89a359dp-10,
+                 c4 = neg ? -0x1.99343027bf8c3p-16 : 0x1.99343027bf8c3p-16;
+    const double x4 = x2 * x2, k2 = c3 + x2 * c4, k1 = c0 + x2 * c1, x6 = x4 * x2, c = k1 + x4 * c2;
+    return (float)(c + x6 * k2);
+}
+__device__ __forceinline__ float libm_sincosf(float y, int which) {
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    double x = (double)y;
+    if (top < 0x3f4u) {                      // |y| < pi/4 (abstop12 of 0x1.921FB6p-1f)
+        if (top < 0x398u) return which ? 1.0f : y;  // |y| < 2^-12
+        return libm_sincosf_poly(x, x * x, false, which);
+    }
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int)r + 0x800000) >> 24;
+    x = x - (double)n * 0x1.921FB54442D18p0;
+    const double sx = ((n + 1) & 2) ? -x : x;   // sign[n & 3] = {1, -1, -1, 1}
+    return libm_sincosf_poly(sx, x * x, (n & 2) != 0, n ^ which);
+}
+
+// sampling configuration of a Radiance step: r2 = r2scale * U (pathtracer.cpp:156,170; 10 or 1), and the
+// reading of cos/sin(float) at :155,162 (VMX_SAMPLING_LIBM_DOUBLE)
+struct SampCfg {
+    float r2scale;
+    uint32_t libm_double;
+};
+
 // The loop body is split where the cosine-lobe branch needs cos/sin of r1 (double precision, a few
 // hundred instructions): only ~10 % of the paths get there (the others end, or bounce off the
 // mirror lobe) — a wave in which no lane gets there skips them.
@@ -546,7 +587,20 @@ struct ShadeMid {
     float sx, sy, sz;  // origin of the next ray
     float r2s, q;      // sqrt(r2), sqrt(1 - r2)
     double angle;      // r1
+    float angle_f;     // r1 where the reference holds it in a float (material branch, :155); NaN marks the double branch
 };
+// cos and sin of a path's r1 under the configured reading
+__device__ __forceinline__ void shade_trig(const ShadeMid &m, uint32_t libm_double, float &cs, float &sn) {
+    if (!libm_double && m.angle_f == m.angle_f) {
+        cs = libm_sincosf(m.angle_f, 1);
+        sn = libm_sincosf(m.angle_f, 0);
+    } else {
+        // one range reduction for both (sincos returns exactly sin and cos: same kernels; the frame tests would show)
+        double s, c;
+        sincos(m.angle, &s, &c);
+        cs = (float)c, sn = (float)s;
+    }
+}
 enum { kPathEnded = 0, kPathNextRay = 1, kPathNeedsTrig = 2 };
 
 __device__ __forceinline__ bool path_set_ray(Path &P, StepFlags &fl, float sx, float sy, float sz, float ndx, float ndy,
@@ -563,6 +617,7 @@ __device__ __forceinline__ bool path_set_ray(Path &P, StepFlags &fl, float sx, f
 template <bool TEX>
 __device__ __forceinline__ int path_shade_begin(const SceneDev &sc, float r2scale, Path &P, const CastResult &c,
                                                 StepFlags &fl, ShadeMid &m) {
+    m.angle_f = __uint_as_float(0x7FC00000u);
     fl.tri_hit = c.slot >= 0;
     fl.continues = false;
     if (!(c.nearest < kInf)) return kPathEnded;  // pathtracer.cpp:36-41
@@ -611,6 +666,7 @@ __device__ __forceinline__ int path_shade_begin(const SceneDev &sc, float r2scal
         const float r2 = (float)((double)r2scale * rng_u01(P.rng));
         m.r2s = sqrtf(r2);
         m.angle = (double)r1;
+        m.angle_f = r1;
         m.q = sqrtf(1.0f - r2);
     } else {  // :166-196 — nearest hit is a sphere and the BVH hit nothing
         const double r1 = 6.283185307179586 * rng_u01(P.rng);
@@ -649,23 +705,22 @@ __device__ __forceinline__ bool path_shade_end(Path &P, const CastResult &c, Ste
 
 // Radiance's loop body after RayCast in one piece (the fused kernels)
 template <bool TEX>
-__device__ __forceinline__ bool path_shade(const SceneDev &sc, float r2scale, Path &P, const CastResult &c,
+__device__ __forceinline__ bool path_shade(const SceneDev &sc, SampCfg cfg, Path &P, const CastResult &c,
                                            StepFlags &fl) {
     ShadeMid m;
-    const int st = path_shade_begin<TEX>(sc, r2scale, P, c, fl, m);
+    const int st = path_shade_begin<TEX>(sc, cfg.r2scale, P, c, fl, m);
     if (st != kPathNeedsTrig) return st == kPathNextRay;
-    // one range reduction for both (sincos returns exactly sin and cos: same kernels; the frame tests would show)
-    double sn, cs;
-    sincos(m.angle, &sn, &cs);
-    return path_shade_end(P, c, fl, m, (float)cs, (float)sn);
+    float sn, cs;
+    shade_trig(m, cfg.libm_double, cs, sn);
+    return path_shade_end(P, c, fl, m, cs, sn);
 }
 
 template <bool COUNT>
-__device__ __forceinline__ bool path_step(const SceneDev &sc, float r2scale, Path &P, uint2 *stk,
+__device__ __forceinline__ bool path_step(const SceneDev &sc, SampCfg cfg, Path &P, uint2 *stk,
                                           StepFlags &fl, Cnt &cnt) {
     CastResult c;
     ray_cast<COUNT>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, stk, c, cnt);
-    return path_shade<false>(sc, r2scale, P, c, fl);
+    return path_shade<false>(sc, cfg, P, c, fl);
 }
 
 // ---------------------------------------------------------------------------
@@ -975,6 +1030,14 @@ __global__ void k_primary_ids(SceneDev sc, FrameDev fr, uint32_t k, int32_t *__r
     }
 }
 
+// parity hook: cosf / sinf as the shading kernels evaluate them under the default reading
+__global__ void k_trig(const float *__restrict__ x, uint32_t n, float *__restrict__ cs, float *__restrict__ sn) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        cs[i] = libm_sincosf(x[i], 1);
+        sn[i] = libm_sincosf(x[i], 0);
+    }
+}
+
 __global__ void k_init_pixels(PixelStateDev px, uint32_t npix) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
@@ -1026,7 +1089,7 @@ __global__ void k_primary(SceneDev sc, FrameDev fr, const unsigned int *__restri
         bool alive = false;
         if (run) {
             fl.was_ray = true;
-            alive = path_step<COUNT>(sc, fr.r2scale, P, stk, fl, c0);
+            alive = path_step<COUNT>(sc, SampCfg{fr.r2scale, fr.libm_double}, P, stk, fl, c0);
         }
         tally_add(tl, fl, run, 1u);
         if (LOOP) {
@@ -1035,7 +1098,7 @@ __global__ void k_primary(SceneDev sc, FrameDev fr, const unsigned int *__restri
                 bool still = false;
                 if (alive) {
                     f2.was_ray = finite3(P.dx, P.dy, P.dz);
-                    still = path_step<COUNT>(sc, fr.r2scale, P, stk, f2, c1);
+                    still = path_step<COUNT>(sc, SampCfg{fr.r2scale, fr.libm_double}, P, stk, f2, c1);
                 }
                 tally_add(tl, f2, alive, 0u);
                 alive = still;
@@ -1073,7 +1136,7 @@ __global__ void k_radiance_init(const float *__restrict__ o, const float *__rest
 
 // one Radiance step (LOOP: all remaining steps) for every queued path
 template <bool COUNT, bool LOOP>
-__global__ void k_bounce(SceneDev sc, float r2scale, QueueDev qin, uint32_t max_chunks, QueueDev qout,
+__global__ void k_bounce(SceneDev sc, SampCfg r2scale, QueueDev qin, uint32_t max_chunks, QueueDev qout,
                          float4 *__restrict__ rad, DevCounters *ctr) {
     extern __shared__ uint2 lds_stack[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1274,7 +1337,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                     CastResult c;
                     cast_finish<true, false>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, best, slot, c, s_geom);
                     fl.was_ray = is_ray;
-                    alive = path_shade<TEX>(sc, fr.r2scale, P, c, fl);
+                    alive = path_shade<TEX>(sc, SampCfg{fr.r2scale, fr.libm_double}, P, c, fl);
                     if (!alive) {
                         rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
                         has = false;
@@ -2406,9 +2469,9 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
         // (gathering the block's ~10 % of angles in LDS to evaluate cos/sin in full waves was measured:
         // the three barriers it needs cost what it saves)
         if (st == kPathNeedsTrig) {
-            double sn, cs;
-            sincos(mid.angle, &sn, &cs);  // one range reduction for both; bit-identical to cos() and sin()
-            alive = path_shade_end(P, c, fl, mid, (float)cs, (float)sn);
+            float sn, cs;
+            shade_trig(mid, fr.libm_double, cs, sn);
+            alive = path_shade_end(P, c, fl, mid, cs, sn);
         }
         if (alive) {
             ray_store(pa, pid, P);
@@ -2843,6 +2906,11 @@ int launch_primary_ids(const SceneDev &sc, const FrameDev &fr, uint32_t k, int32
     return launch_status();
 }
 
+int launch_trig(const float *x, uint32_t n, float *cs, float *sn, void *stream) {
+    hipLaunchKernelGGL(k_trig, dim3(std::min<uint32_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, n, cs, sn);
+    return launch_status();
+}
+
 int launch_init_pixels(PixelStateDev px, uint32_t npix, void *stream) {
     hipLaunchKernelGGL(k_init_pixels, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream, px, npix);
     return launch_status();
@@ -2880,10 +2948,11 @@ int launch_radiance_init(const float *o, const float *d, uint32_t n, uint64_t se
     return launch_status();
 }
 
-int launch_bounce(const SceneDev &sc, float r2scale, QueueDev qin, uint32_t max_chunks, QueueDev qout, void *rad,
-                  DevCounters *counters, bool count, bool loop_to_end, bool, LaunchCfg cfg, void *stream) {
+int launch_bounce(const SceneDev &sc, float r2scale_f, uint32_t libm_double, QueueDev qin, uint32_t max_chunks, QueueDev qout,
+                  void *rad, DevCounters *counters, bool count, bool loop_to_end, bool, LaunchCfg cfg, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     dim3 g(cfg.grid), b(cfg.block);
+    const SampCfg r2scale{r2scale_f, libm_double};
 #define VMX_GO(C, L)                                                                                       \
     hipLaunchKernelGGL((k_bounce<C, L>), g, b, cfg.lds_bytes, s, sc, r2scale, qin, max_chunks, qout,      \
                        (float4 *)rad, counters)

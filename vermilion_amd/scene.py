@@ -31,7 +31,7 @@ def make_camera(position, rotation_deg, width, height, spp, back_distance=6.0, b
 
 def make_opts(seed=1, early_stop=True, sampling=L.VMX_SAMPLING_PARITY, rank=0, world=1, stripe_rows=16,
               samples_per_batch=0, collect_counters=False, pipeline=0, max_paths=0, tail_threshold=0,
-              refill_min=0, shade_min=0, leaf_min=0, lds_entries=0):
+              refill_min=0, shade_min=0, reorder=0, lds_entries=0):
     o = L.Opts()
     o.seed = int(seed)
     o.early_stop = 1 if early_stop else 0
@@ -44,7 +44,7 @@ def make_opts(seed=1, early_stop=True, sampling=L.VMX_SAMPLING_PARITY, rank=0, w
     o.reserved[2] = int(tail_threshold)
     o.reserved[3] = int(refill_min)    # k_paths: refill when this many lanes idle (0 -> 16)
     o.reserved[4] = int(shade_min)     # k_paths: shade when this many lanes finished (0 -> 16)
-    o.reserved[5] = int(leaf_min)      # k_paths: triangle step when this many lanes sit at a leaf (0 -> 16)
+    o.reserved[5] = int(reorder)       # bounce reordering key (vmx_api.cpp: Tuning::sort_mode); 0 = the library's default
     o.reserved[6] = int(lds_entries)   # stack levels kept in LDS, all kernels (0 -> 8 camera / 13 bounce / 10 fused); deeper ones spill to HBM
     return o
 
