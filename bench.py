@@ -36,6 +36,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # VALU issue roof: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz max clock
 # (MI355X_MICROARCH.md "Wave scheduling", "Per-instruction cycle constants") -> wave-level instructions per second
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
+# Work-based roofline: arithmetic + comparison instructions ONE lane needs for one
+# inner-node visit (both child boxes, bbox.cpp:70-83 + the decisions of bvh.cpp:103-114) and for one triangle test
+# (triangle.cpp:4-54) in each traversal kernel's data layout; min3/max3 and the division count as one each.
+#   camera rays (origin folded into the per-frame tables): 12 mul + 4 min3/max3 + 4 cmp;  cross 9 + det 5 + div 1 +
+#     u 6 + v 6 + t 1 + 8 cmp
+#   bounce rays: 12 sub + 12 mul + 12 min/max + 4 min3/max3 + 4 cmp;  cross 9 + det 5 + div 1 + tvec 3 + u 6 +
+#     cross 9 + v 6 + t 6 + 8 cmp
+A_INNER = {"trace_camera": 20, "trace_bounce": 44}
+A_TRI = {"trace_camera": 36, "trace_bounce": 53}
 KERNEL_TEXT = {
     "trace_camera": "k_trace_w<0> (persistent BVH traversal of the camera rays)",
     "trace_bounce": "k_trace_w<1> (persistent BVH traversal of a bounce generation, quad-cooperative record fetch)",
@@ -73,10 +82,16 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (frames travel through host memory)")
     ap.add_argument("--device", type=int, default=-1, help="force this HIP device for every rank (rehearsal)")
+    ap.add_argument("--multi", default="", help="one process, several devices behind the C ABI (vmx_multi_*): comma-separated "
+                    "device list, e.g. 0,1,2,3 (a device may repeat: rehearsal on one GPU); the gather and the assembly on the "
+                    "first device are inside the timed step.  Not combined with torch.distributed.run")
+    ap.add_argument("--corrected-spp", type=int, default=64, help="spp of the corrected-sampling (r2 = U) frame")
     ap.add_argument("--reorder", type=lambda v: int(v, 0), default=0,
                     help="experiment: bounce reordering key (vmx_opts.reserved[5], tools/sort_probe.py); 0 = library default")
     args = ap.parse_args()
 
+    if args.multi:
+        return main_multi(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -160,6 +175,30 @@ def main():
         es_k = max(1, min(args.steps, 3))
         es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
 
+    # `corrected` sampling (r2 = U: a real cosine-weighted lobe, pathtracer.cpp:156,170 with the factor 10 removed):
+    # SURVEY 8(d) / BASELINE.md §3 ask for it beside `parity`.  Bounces dominate here (~25 rays per sample).
+    corr_info = None
+    if world == 1 and not args.no_extras and args.corrected_spp >= 4:
+        ccam = va.make_camera(c["position"], c["rotation_deg"], W, H, args.corrected_spp, back_size=(3.6, 3.6 * H / W))
+        copts = va.make_opts(seed=args.seed, early_stop=False, sampling=va.VMX_SAMPLING_CORRECTED)
+        sc.render_device(ccam, copts, local.data_ptr(), stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        cs_ = sc.render_device(ccam, copts, local.data_ptr(), stream)
+        torch.cuda.synchronize(dev)
+        cdt = time.perf_counter() - t0
+        ck = sc.timings()
+        crays = cs_["rays_primary"] + cs_["rays_secondary"]
+        corr_info = {
+            "what": "same scene and camera with r2 = U instead of the reference's r2 = 10 U (VMX_SAMPLING_CORRECTED), fixed "
+                    f"{args.corrected_spp} spp: no image-parity claim against the reference, oracle parity only "
+                    "(tests/test_gpu_parity.py)",
+            "spp": args.corrected_spp, "ms_per_frame": round(cdt * 1e3, 3), "Mrays_per_s": round(crays / cdt / 1e6, 2),
+            "rays_per_frame": int(crays), "rays_per_sample": round(crays / max(cs_["samples"], 1), 2),
+            "kernel_ms": {k: round(v["ms"], 3) for k, v in ck.items() if v["launches"]},
+            "kernel_launches": {k: int(v["launches"]) for k, v in ck.items() if v["launches"]},
+        }
+
     # §8 f-4: the engine's default integrator on the same scene and camera (BruteForceTracer, most pixels stop after
     # 3 samples): device time of one frame
     bf_info = None
@@ -234,6 +273,22 @@ def main():
             except Exception:
                 prof = None
 
+        # what the two traversal kernels had to do in one step (counters pass of this exact frame): the camera-ray
+        # kernel traces every depth-0 ray; the first bounce generation (the paths that continue after their first
+        # hit) goes through k_trace_w<1>, later generations through the fused tail — the instrumented kernels count
+        # per stage, so the bounce kernel's share is the stage's per-ray averages x its rays
+        work = {}
+        if world == 1:
+            pr, bo = cst["primary"], cst["bounce"]
+            work["trace_camera"] = {"rays": pr["rays"], "inner_visits": pr["inner_visits"], "tri_tests": pr["tri_tests"],
+                                    "alg_bytes": trace_alg_bytes(pr), "from": "counters pass, depth-0 stage"}
+            if bo["rays"] and klaunch.get("trace_bounce"):
+                g1 = min(pr["continued"], bo["rays"])
+                f = g1 / bo["rays"]
+                work["trace_bounce"] = {"rays": g1, "inner_visits": bo["inner_visits"] * f, "tri_tests": bo["tri_tests"] * f,
+                                        "alg_bytes": trace_alg_bytes(bo) * f,
+                                        "from": "counters pass, bounce stage averages x rays of the first generation"}
+
         def kernel_roof(name):
             """VALU-issue roofline of one kernel: wave-level VALU instructions per launch (rocprofv3 PMC of this
             exact frame, profiles/counters.json) / the launch duration measured here"""
@@ -261,6 +316,26 @@ def main():
                           if "l1_accesses_per_launch" in d else None,
                           "hbm_frac_measured": round(d["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                           if "hbm_bytes_per_launch" in d else None})
+                w = work.get(name)
+                if w:
+                    # lane-operations the VALU executed per ray, and per-launch bytes through the vector L1 (64 B per
+                    # tag lookup) and the scalar cache (64 B per s_load_dwordx16) next to the algorithmic bytes
+                    r["valu_lane_ops_per_ray"] = round(d["valu_wave_insts_per_launch"] * 64 * d.get("valu_lane_utilization", 1.0)
+                                                       / max(w["rays"], 1), 1)
+                    c = (prof or {}).get(name, {}).get("counters", {})
+                    r["cache_bytes_per_launch"] = {
+                        "vector_l1": int(d["l1_accesses_per_launch"] * 64) if "l1_accesses_per_launch" in d else None,
+                        "scalar_cache": int(c["SQ_INSTS_SMEM"] * 64) if "SQ_INSTS_SMEM" in c else None,
+                        "algorithmic": int(w["alg_bytes"])}
+            w = work.get(name)
+            if w and avg_ms > 0:
+                # work against the roof: the lane-operations the reference's tests NEED, as full 64-lane instructions,
+                # over the launch time and the VALU issue peak — cannot exceed 1, does not grow with wasted instructions
+                need = w["inner_visits"] * A_INNER[name] + w["tri_tests"] * A_TRI[name]
+                r["useful_valu_frac"] = round(need / 64 / (avg_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
+                r["useful_lane_ops_per_ray"] = round(need / max(w["rays"], 1), 1)
+                r["work"] = {"rays": int(w["rays"]), "inner_visits": int(w["inner_visits"]), "tri_tests": int(w["tri_tests"]),
+                             "A_inner": A_INNER[name], "A_tri": A_TRI[name], "from": w["from"]}
             return r
 
         roof = kernel_roof(dominant)
@@ -268,6 +343,9 @@ def main():
             roof.update({"bound": "valu_issue", "achieved": None, "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
                          "unit": "Gwave-inst/s", "frac": None, "traffic": None,
                          "note": "profiles/counters.json holds no counters for this workload"})
+        roof["useful_valu_frac_what"] = ("(inner_visits x A_inner + tri_tests x A_tri) / 64 / launch duration / VALU issue peak: the "
+                                         "share of the issue roof spent on arithmetic the reference's tests need (frac counts "
+                                         "every instruction issued)")
         roof["source"] = "profiles/counters.json (rocprofv3 --pmc, tools/pmc.sh + tools/make_counters.py) x live hipEvent durations"
         roof["other_kernels"] = {k: kernel_roof(k) for k in ("trace_camera", "trace_bounce", "shade_camera", "tail")
                                  if k != dominant and kms.get(k, 0) > 0}
@@ -326,10 +404,17 @@ def main():
                 "Mrays_per_s": round(es_rays / es_dt / 1e6, 2),
                 "rays_per_frame": int(es_rays / es_k),
                 "passes": es_stats[0]["passes"],
+                "kernel_ms": {k: round(sum(s["kernels"][k]["ms"] for s in es_stats) / es_k, 3)
+                              for k in es_stats[0]["kernels"] if es_stats[0]["kernels"][k]["launches"]},
+                "kernel_launches": {k: int(es_stats[0]["kernels"][k]["launches"])
+                                    for k in es_stats[0]["kernels"] if es_stats[0]["kernels"][k]["launches"]},
+                "device_ms": round(sum(s["ms_device"] for s in es_stats) / es_k, 3),
             }
         if q_info:
             out["quality_bvh"] = q_info
             out["quality_bvh_gpu_built"] = p_info
+        if corr_info:
+            out["corrected_frame"] = corr_info
         if bf_info:
             out["bruteforce_frame"] = bf_info
         if world == 1 and not args.no_cpu_baseline:
@@ -339,6 +424,73 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_multi(args):
+    """One process, several devices behind the C ABI (vmx_multi_*, what a Vermilion main.cpp would call): every device
+    renders its interleaved stripes, pushes them device-to-device into the gather buffer on the first device, which
+    de-interleaves; all of it inside the timed step.  Same JSON line as the torch.distributed path."""
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        sys.exit("bench.py --multi is a single process: do not launch it through torch.distributed.run")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU path)")
+    devices = [int(d) for d in args.multi.split(",") if d != ""]
+    world = len(devices)
+    gen, camf = scenes.SCENES[args.scene]
+    pos, nrm, uv = gen()
+    c = camf()
+    W, H, spp = args.width, args.height, args.spp
+    cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
+    stripe = 16 if world <= 4 else 4
+    root = torch.device("cuda", devices[0])
+    frame = torch.empty((H, W, 5), dtype=torch.float32, device=root)
+    ms = va.MultiScene(pos, nrm, uv, devices=devices)
+    opts = va.make_opts(seed=args.seed, early_stop=False, sampling=va.VMX_SAMPLING_PARITY, stripe_rows=stripe)
+
+    def sync():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(torch.device("cuda", d))
+
+    for _ in range(args.warmup):
+        ms.render_device(cam, opts, frame.data_ptr())
+    gc.collect()
+    gc.disable()
+    sync()
+    t0 = time.perf_counter()
+    stats = [ms.render_device(cam, opts, frame.data_ptr()) for _ in range(args.steps)]
+    sync()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    rays = float(sum(s["rays_primary"] + s["rays_secondary"] for s in stats))
+    es_opts = va.make_opts(seed=args.seed, early_stop=True, stripe_rows=stripe)
+    ms.render_device(cam, es_opts, frame.data_ptr())
+    sync()
+    t0 = time.perf_counter()
+    es = ms.render_device(cam, es_opts, frame.data_ptr())
+    sync()
+    es_dt = time.perf_counter() - t0
+    out = {
+        "metric": "Mrays/sec (primary+secondary), 1920x1080 Sponza", "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{args.scene} ({ms.ntris} tris, procedural Sponza stand-in) {W}x{H} {spp}spp, reference sampling "
+                        "(r2=10U), fixed spp (early stop off), reference sphere table",
+            "rays_per_frame": int(rays / args.steps),
+            "parallelism": f"one process, vmx_multi over devices {devices}, stripes{stripe}x{world}, device-to-device gather "
+                           "on the first device",
+            "distinct_devices": len(set(devices)),
+        },
+        "roofline": {"bound": "valu_issue", "achieved": None, "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "Gwave-inst/s",
+                     "frac": None, "traffic": None,
+                     "note": "per-kernel counters are a single-device figure: see the N=1 line (python bench.py)"},
+        "slowest_device_ms_per_step": round(sum(s["ms_device"] for s in stats) / args.steps, 3),
+        "reference_frame": {"what": "same frame with the reference's early-stop rule on (pathtracer.cpp:290-311)",
+                            "ms_per_frame": round(es_dt * 1e3, 3),
+                            "Mrays_per_s": round((es["rays_primary"] + es["rays_secondary"]) / es_dt / 1e6, 2)},
+    }
+    print(json.dumps(out), flush=True)
+    ms.close()
 
 
 def cpu_baseline(pos, nrm, uv, c, W, H, spp, seed):

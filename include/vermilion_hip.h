@@ -305,6 +305,10 @@ int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32
                      vmx_multi **out);
 int vmx_multi_destroy(vmx_multi *m);
 uint32_t vmx_multi_world(const vmx_multi *m);
+/* per entry of the device list: its device, and how its stripes reach devices[0] — 2 same device, 1 direct peer
+ * copy (xGMI), 0 staged through the host (peer access unavailable; a warning went to stderr at creation).
+ * Either array may be NULL; each holds vmx_multi_world() ints. */
+int vmx_multi_routes(const vmx_multi *m, int *devices, int *routes);
 int vmx_multi_bind_texture(vmx_multi *m, const float *data, uint32_t width, uint32_t height, uint32_t channels);
 /* whole frame (W*H*5 floats) into a caller-owned HOST buffer / into DEVICE memory on devices[0];
  * stats: rays and samples summed over the devices, times = the slowest device's */

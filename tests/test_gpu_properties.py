@@ -198,3 +198,24 @@ def test_per_kernel_timings_of_the_last_render(sponza):
     assert t2["fused"]["launches"] >= 1 and t2["trace_camera"]["launches"] == 0
     _, _ = sponza.render_bruteforce(sponza_cam(96, 64, 8), va.make_opts(seed=2))
     assert sponza.timings()["bruteforce"]["launches"] == 1
+
+
+def test_pass_size_follows_the_memory_budget(sponza, monkeypatch):
+    """render_impl sizes a pass from hipMemGetInfo (free memory + what the scene's workspace
+    already holds) instead of assuming 67 GB of path state fit; VMX_MEM_BUDGET_MB simulates a small device.
+    Frames do not depend on the pass size."""
+    cam = sponza_cam(640, 360, 16)
+    for es in (False, True):
+        opts = va.make_opts(seed=3, early_stop=es)
+        monkeypatch.delenv("VMX_MEM_BUDGET_MB", raising=False)
+        a, sa = sponza.render(cam, opts)
+        monkeypatch.setenv("VMX_MEM_BUDGET_MB", "200")  # room for ~1.5 samples per pixel of path state
+        b, sb = sponza.render(cam, opts)
+        assert np.array_equal(bits(a), bits(b))
+        assert sb["passes"] > sa["passes"] and sb["samples"] == sa["samples"]
+        if not es:
+            assert sa["passes"] == 1 and sb["passes"] == 16
+        monkeypatch.setenv("VMX_MEM_BUDGET_MB", "1")  # below the fixed part: one sample per pixel and pass still renders
+        c, sc_ = sponza.render(cam, opts)
+        assert np.array_equal(bits(a), bits(c))
+    monkeypatch.delenv("VMX_MEM_BUDGET_MB", raising=False)

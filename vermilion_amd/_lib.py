@@ -174,6 +174,7 @@ SYMBOLS = {
                                   C.c_uint32, C.POINTER(_P)]),
     "vmx_multi_destroy": (C.c_int, [_P]),
     "vmx_multi_world": (C.c_uint32, [_P]),
+    "vmx_multi_routes": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vmx_multi_bind_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vmx_multi_render": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),
     "vmx_multi_render_device": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),

@@ -36,7 +36,7 @@ bool build_bvh_sah(const float *pos, const float *nrm, const float *uv, uint32_t
 // device-record emission.  The product buffers (`geom` = inner records then triangle records, `attrs`) are
 // device memory handed to the scene; the hierarchy arrays stay in `arena` for lbvh_export_flat.
 struct LbvhDevice {
-    void *arena = nullptr;  // inputs, temporaries, hierarchy
+    void *arena = nullptr;  // the hierarchy (kept for lbvh_export_flat); inputs and temporaries are freed by the build
     size_t arena_bytes = 0;
     void *geom = nullptr;   // InnerRecord[n_inner] then TriRecord[ntris] (+ 64 bytes of padding)
     size_t geom_bytes = 0;

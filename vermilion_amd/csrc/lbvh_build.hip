@@ -419,7 +419,8 @@ void lbvh_release(LbvhDevice &d) {
 
 // The whole build on the device: upload -> Morton keys -> radix sort -> Karras hierarchy -> bottom-up fit ->
 // InnerRecord / TriRecord / AttrRecord emission.  Nothing comes back to the host except the root's height
-// (for the traversal stack depth); the hierarchy arrays stay in `out.arena` for lbvh_export_flat.
+// (for the traversal stack depth); the hierarchy arrays stay in `out.arena` for lbvh_export_flat, everything else
+// the build needed is released before it returns.
 static bool build_device(const float *pos, const float *nrm, const float *uv, uint32_t ntris, uint32_t leaf_size,
                          int device, bool ploc, LbvhDevice &out, std::string &err) {
     if (!check_bvh_input(pos, nrm, ntris, leaf_size, err)) return false;
@@ -431,13 +432,19 @@ static bool build_device(const float *pos, const float *nrm, const float *uv, ui
     size_t tmp_bytes = 0;
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr,
                                               (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 63));
-    // one arena for inputs, temporaries and the hierarchy (a hipMalloc per array costs more than the kernels)
+    // two allocations (a hipMalloc per array costs more than the kernels): `arena` keeps the hierarchy for
+    // lbvh_export_flat (68 B per triangle, counted in vmx_scene_desc.device_bytes); `scratch` holds the input copies,
+    // keys, sort / scan temporaries and the PLOC cluster buffers (250-400 B per triangle) and is freed when the
+    // records have been written
     const size_t in_floats = (size_t)n * (uv ? 24 : 18);
-    size_t arena_bytes = 0;
-    auto add = [&](size_t bytes) { arena_bytes += (bytes + 255) & ~(size_t)255; };
-    add(in_floats * 4), add((size_t)n * 8), add((size_t)n * 8), add((size_t)n * 4), add((size_t)n * 4);  // inputs, keys x2, ids x2
-    for (int k = 0; k < 6; ++k) add(ni * 4);                                                             // left right first last pint height
-    add((size_t)n * 4), add(ni * 4), add((size_t)n * 24), add(ni * 24), add(256), add(tmp_bytes);        // pleaf arrivals leaf_box node_box bounds tmp
+    size_t arena_bytes = 0, scratch_bytes = 0;
+    auto keep = [&](size_t bytes) { arena_bytes += (bytes + 255) & ~(size_t)255; };
+    auto add = [&](size_t bytes) { scratch_bytes += (bytes + 255) & ~(size_t)255; };
+    keep((size_t)n * 4);                                     // ids
+    for (int k = 0; k < 4; ++k) keep(ni * 4);                // left right first last
+    keep((size_t)n * 24), keep(ni * 24);                     // leaf_box node_box
+    add(in_floats * 4), add((size_t)n * 8), add((size_t)n * 8), add((size_t)n * 4);  // inputs, keys x2, ids
+    add(ni * 4), add(ni * 4), add((size_t)n * 4), add(ni * 4), add(256), add(tmp_bytes);  // pint height pleaf arrivals bounds tmp
     size_t scan_bytes = 0;
     if (ploc) {
         LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, n));
@@ -447,18 +454,25 @@ static bool build_device(const float *pos, const float *nrm, const float *uv, ui
     }
     LB_TRY(hipMalloc(&out.arena, arena_bytes));
     out.arena_bytes = arena_bytes;
-    unsigned char *cur = (unsigned char *)out.arena;
+    struct Scratch {  // freed on every way out of this function
+        void *p = nullptr;
+        ~Scratch() {
+            if (p) (void)hipFree(p);
+        }
+    } scratch;
+    LB_TRY(hipMalloc(&scratch.p, scratch_bytes));
+    unsigned char *kcur = (unsigned char *)out.arena, *cur = (unsigned char *)scratch.p;
+    out.ids = carve<uint32_t>(kcur, n);
+    out.left = carve<uint32_t>(kcur, ni), out.right = carve<uint32_t>(kcur, ni);
+    out.first = carve<uint32_t>(kcur, ni), out.last = carve<uint32_t>(kcur, ni);
+    out.leaf_box = carve<float>(kcur, (size_t)n * 6), out.node_box = carve<float>(kcur, ni * 6);
     float *d_in = carve<float>(cur, in_floats);
     float *d_pos = d_in, *d_nrm = d_in + (size_t)n * 9, *d_uv = uv ? d_in + (size_t)n * 18 : nullptr;
     unsigned long long *d_keys = carve<unsigned long long>(cur, n), *d_keys2 = carve<unsigned long long>(cur, n);
     uint32_t *d_ids = carve<uint32_t>(cur, n);
-    out.ids = carve<uint32_t>(cur, n);
-    out.left = carve<uint32_t>(cur, ni), out.right = carve<uint32_t>(cur, ni);
-    out.first = carve<uint32_t>(cur, ni), out.last = carve<uint32_t>(cur, ni);
     uint32_t *d_pint = carve<uint32_t>(cur, ni), *d_height = carve<uint32_t>(cur, ni);
     uint32_t *d_pleaf = carve<uint32_t>(cur, n);
     unsigned int *d_arr = carve<unsigned int>(cur, ni);
-    out.leaf_box = carve<float>(cur, (size_t)n * 6), out.node_box = carve<float>(cur, ni * 6);
     int *d_bounds = carve<int>(cur, 64);
     unsigned char *d_tmp = carve<unsigned char>(cur, tmp_bytes);
 

@@ -9,11 +9,15 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -142,7 +146,8 @@ struct vmx_scene {
     int num_cus = 0;
     HostBvh bvh;        // host-built trees: flat layout + device records; device-built (LBVH): filled on demand
     LbvhDevice lbvh;    // VMX_BVH_LBVH: the tree was built and flattened on the device (lbvh_build.hip)
-    bool device_built = false, flat_ready = true;
+    bool device_built = false;
+    std::atomic<bool> flat_ready{true};
     uint32_t n_inner = 0;  // inner record slots on the device
     uint32_t ntris = 0, leaf_size = 4;
     std::vector<vmx_sphere> spheres;
@@ -588,6 +593,28 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     uint32_t smax = (uint32_t)std::max<uint64_t>(1, max_paths / npix);
     if (opts->samples_per_batch) smax = opts->samples_per_batch;
     smax = std::min(smax, fr.kmax);
+    // ... and never more than the device can hold right now (a shared or partitioned GPU, a second scene): a pass
+    // needs `per_path` bytes per path slot; the budget is the free memory plus what this scene's workspace already
+    // holds for the same purpose, less a tenth.  Frames do not depend on the pass size, so smaller passes are free of
+    // consequences other than time.  VMX_MEM_BUDGET_MB lowers the budget (tests, co-tenancy).
+    uint64_t mem_budget = 0;
+    const size_t n_pad_cap = ((size_t)npix + 63u) & ~(size_t)63u;
+    if (!opts->samples_per_batch && !legacy) {
+        const size_t per_path = 16 + 64 + 8 + 16 + 8 + (sc->dev.tex ? 16 : 0) + (tn.sort_mode ? 12 : 0);
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t held = ws.rayA.n + ws.state.n + ws.hit.n + ws.rad.n + ws.thr.n + (ws.ids[0].n + ws.ids[1].n) * 4 +
+                            (ws.sort_keys[0].n + ws.sort_keys[1].n + ws.ids_sorted.n) * 4;
+        mem_budget = (uint64_t)((free_b + held) / 10 * 9);
+        if (const char *e = std::getenv("VMX_MEM_BUDGET_MB")) {
+            const uint64_t cap = std::strtoull(e, nullptr, 10) << 20;
+            if (cap) mem_budget = std::min(mem_budget, cap);
+        }
+        const uint64_t fixed = (uint64_t)npix * 48 + ((uint64_t)sc->n_inner * 512 + (uint64_t)sc->ntris * 64) + (64ull << 20);
+        const uint64_t fit = mem_budget > fixed ? (mem_budget - fixed) / per_path : 0;
+        const uint32_t s_fit = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, fit / n_pad_cap), fr.kmax);
+        if (s_fit < smax) smax = s_fit;
+    }
     // under early stop no group is larger than the first one: nmin + 1 samples plus the first samples of the following strata
     if (fr.early_stop) smax = std::min(smax, fr.nmin + 1 + (fr.quarter ? fr.kmax / fr.quarter - 1u : 0u));
     if (!fr.early_stop && !opts->samples_per_batch) {
@@ -616,6 +643,9 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     int tb = 1, tbb = 1;  // blocks per CU of the trace kernel: camera rays, bounce rays
     if (split_any) {
         rc = ensure_paths(sc, (size_t)n_pad_max * smax, pa, qi);
+        if (rc == VMX_ERR_NOMEM && smax > 1 && !opts->samples_per_batch)
+            return fail(VMX_ERR_NOMEM, "hipMalloc failed for the path arrays although " + std::to_string(mem_budget >> 20) +
+                                           " MB were reported free: set VMX_MEM_BUDGET_MB or vmx_opts.reserved[1] (paths per pass)");
         if (rc) return rc;
         HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_primary + 1) * 512, count, &tb));
         HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, &tbb));
@@ -915,7 +945,7 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
     std::string err;
     bool built;
     if (builder == VMX_BVH_LBVH || builder == VMX_BVH_PLOC) {
-        sc->device_built = true, sc->flat_ready = false;
+        sc->device_built = true, sc->flat_ready.store(false);
         built = builder == VMX_BVH_PLOC ? build_bvh_ploc_device(pos, nrm, uv, ntris, sc->leaf_size, device, sc->lbvh, err)
                                         : build_bvh_lbvh_device(pos, nrm, uv, ntris, sc->leaf_size, device, sc->lbvh, err);
     } else {
@@ -924,7 +954,11 @@ int vmx_scene_create_ex(const float *pos, const float *nrm, const float *uv, uin
     }
     if (!built) {
         lbvh_release(sc->lbvh);
-        const int code = err.find("deeper") != std::string::npos ? VMX_ERR_DEPTH : VMX_ERR_INVALID;
+        // the device builders report HIP failures as "LBVH builder: <call>: <hipGetErrorString>"
+        int code = VMX_ERR_INVALID;
+        if (err.find("deeper") != std::string::npos) code = VMX_ERR_DEPTH;
+        else if (err.rfind("LBVH builder: hip", 0) == 0)
+            code = (err.find("hipMalloc") != std::string::npos || err.find("out of memory") != std::string::npos) ? VMX_ERR_NOMEM : VMX_ERR_HIP;
         delete sc;
         return fail(code, err);
     }
@@ -987,12 +1021,12 @@ int vmx_scene_bind_texture(vmx_scene *sc, const float *data, uint32_t width, uin
 // device-built trees: the reference's flat layout is produced on the first request for it
 static int ensure_flat(const vmx_scene *csc) {
     vmx_scene *sc = const_cast<vmx_scene *>(csc);
-    if (sc->flat_ready) return VMX_OK;
+    if (sc->flat_ready.load(std::memory_order_acquire)) return VMX_OK;
     std::lock_guard<std::mutex> lock(sc->mu);
-    if (sc->flat_ready) return VMX_OK;
+    if (sc->flat_ready.load(std::memory_order_relaxed)) return VMX_OK;
     std::string err;
     if (!lbvh_export_flat(sc->lbvh, sc->device, sc->bvh, err)) return fail(VMX_ERR_HIP, err);
-    sc->flat_ready = true;
+    sc->flat_ready.store(true, std::memory_order_release);
     return VMX_OK;
 }
 
@@ -1009,13 +1043,15 @@ int vmx_scene_describe(const vmx_scene *sc, vmx_scene_desc *out) {
     out->max_depth = sc->bvh.max_depth;
     out->stack_entries = sc->dev.stack_entries;
     out->device_bytes = (size_t)sc->n_inner * sizeof(InnerRecord) + (size_t)sc->ntris * sizeof(TriRecord) +
-                        (size_t)sc->ntris * sizeof(AttrRecord) + sc->spheres.size() * sizeof(SphereDev);
+                        (size_t)sc->ntris * sizeof(AttrRecord) + sc->spheres.size() * sizeof(SphereDev) +
+                        (sc->device_built ? sc->lbvh.arena_bytes : 0);  // device-built trees keep their hierarchy arrays
     out->device = sc->device;
     return VMX_OK;
 }
 
 int vmx_scene_timings(const vmx_scene *sc, vmx_timings *out) {
     if (!sc || !out) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(const_cast<vmx_scene *>(sc)->mu);  // a render on another thread rewrites them
     *out = sc->timings;
     return VMX_OK;
 }
@@ -1318,21 +1354,28 @@ int bruteforce_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, 
     std::memset(&stack, 0, sizeof(stack));
     rc = bind_stack(sc, tn, tn.lds_entries, cfg.grid, (uint64_t)npix, stack);
     if (rc) return rc;
+    // (one event pair per kernel: the host reads the long-pixel count between the two, and that round trip is not
+    // device time)
     TimedLaunch tl{ws.events.get(), ws.events.get(), 0, VMX_K_BRUTEFORCE};
     if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(tl.a, s));
     LAUNCH_TRY(launch_bruteforce(sc->dev, fr, ws.active[0].p, npix, flags, d_out, ws.counters.p, ws.rad.p, ws.next_count.p,
                                  stack, cfg, s));
+    HIP_TRY(hipEventRecord(tl.b, s));
+    timed.push_back(tl);
     uint64_t launches = 1;
     unsigned int n_long = 0;  // pixels the break has not stopped within the first samples: a wave each from here
     HIP_TRY(hipMemcpyAsync(&n_long, ws.next_count.p, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (n_long != 0) {
+        TimedLaunch tl2{ws.events.get(), ws.events.get(), 0, VMX_K_BRUTEFORCE};
+        if (!tl2.a || !tl2.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(tl2.a, s));
         LAUNCH_TRY(launch_bruteforce_long(sc->dev, fr, flags, d_out, ws.counters.p, ws.rad.p, ws.next_count.p, n_long, stack, cfg, s));
+        HIP_TRY(hipEventRecord(tl2.b, s));
+        timed.push_back(tl2);
         launches++;
     }
-    HIP_TRY(hipEventRecord(tl.b, s));
-    timed.push_back(tl);
     HIP_TRY(hipEventRecord(ev1, s));
     return finish_stats(sc, s, timed, ev0, ev1, stats, 1, launches, t0);
 }
@@ -1378,8 +1421,53 @@ int vmx_render_bruteforce(const vmx_scene *csc, const vmx_camera *cam, const vmx
 // gather of per-tile framebuffers over xGMI"): a Vermilion main.cpp is a single process, so the
 // sharding must be reachable from the C ABI, not only from one-process-per-GPU launchers.
 // ---------------------------------------------------------------------------
+// one persistent host thread per replica (a render hands each of them its job and waits for all of them)
+struct ReplicaWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = false, quit = false;
+    void start() {
+        th = std::thread([this]() {
+            std::unique_lock<std::mutex> lk(mu);
+            for (;;) {
+                cv.wait(lk, [this]() { return has_job || quit; });
+                if (quit) return;
+                std::function<void()> j = std::move(job);
+                has_job = false;
+                lk.unlock();
+                j();
+                lk.lock();
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void submit(std::function<void()> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j), has_job = true, done = false;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this]() { return done; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+            cv.notify_all();
+        }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct vmx_multi {
     std::vector<vmx_scene *> replica;  // one scene replica per entry of the device list (entries may repeat)
+    std::vector<std::unique_ptr<ReplicaWorker>> worker;
+    // how replica r's stripes reach the root: 2 same device, 1 direct peer copy (xGMI), 0 staged through the host
+    std::vector<int> route;
     DevBuf<float> gathered, frame;     // on the root = replica[0]'s device
     std::mutex mu;
 };
@@ -1407,9 +1495,8 @@ int multi_render(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, floa
     std::vector<int> rc(world, VMX_OK);
     std::vector<std::string> msg(world);
     std::vector<vmx_stats> st(world);
-    std::vector<std::thread> th;
     for (uint32_t r = 0; r < world; ++r) {
-        th.emplace_back([&, r]() {
+        m->worker[r]->submit([&, r]() {
             vmx_scene *sc = m->replica[r];
             vmx_opts o = *opts;
             o.rank = r, o.world = world, o.stripe_rows = stripe;
@@ -1432,7 +1519,7 @@ int multi_render(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, floa
             if (rc[r]) msg[r] = g_err;  // g_err is thread-local
         });
     }
-    for (auto &t : th) t.join();
+    for (uint32_t r = 0; r < world; ++r) m->worker[r]->wait();
     for (uint32_t r = 0; r < world; ++r)
         if (rc[r]) return fail(rc[r], "device " + std::to_string(m->replica[r]->device) + ": " + msg[r]);
 
@@ -1479,6 +1566,7 @@ int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32
     if (rc) return rc;
     vmx_multi *m = new vmx_multi();
     m->replica.push_back(first);
+    m->route.push_back(2);
     int ndev = 0;
     (void)hipGetDeviceCount(&ndev);
     for (uint32_t i = 1; i < ndevices; ++i) {
@@ -1514,14 +1602,29 @@ int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32
         m->replica.push_back(sc);
         // direct peer copies into the root's gather buffer (xGMI); without peer access the runtime stages
         // the copy through the host, which is slower but still correct
+        int route = 2;
         if (devices[i] != devices[0]) {
+            route = 0;
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
                 (void)hipSetDevice(devices[i]);
                 const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                // every non-success return (AlreadyEnabled included: a device listed twice, a second vmx_multi in the
+                // process) stays behind as the thread's last error and would fail the next launch's status check
+                if (e != hipSuccess) (void)hipGetLastError();
+                if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) route = 1;
+                else
+                    std::fprintf(stderr, "vermilion_hip: peer access %d -> %d failed (%s): stripes of device %d are staged "
+                                 "through the host\n", devices[i], devices[0], hipGetErrorString(e), devices[i]);
+            } else {
+                (void)hipGetLastError();
             }
         }
+        m->route.push_back(route);
+    }
+    for (size_t i = 0; i < m->replica.size(); ++i) {
+        m->worker.emplace_back(new ReplicaWorker());
+        m->worker.back()->start();
     }
     *out = m;
     return VMX_OK;
@@ -1529,6 +1632,7 @@ int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32
 
 int vmx_multi_destroy(vmx_multi *m) {
     if (!m) return VMX_OK;
+    for (auto &w : m->worker) w->stop();
     if (!m->replica.empty()) (void)hipSetDevice(m->replica[0]->device);
     m->gathered.release(), m->frame.release();
     for (vmx_scene *sc : m->replica) vmx_scene_destroy(sc);
@@ -1537,6 +1641,15 @@ int vmx_multi_destroy(vmx_multi *m) {
 }
 
 uint32_t vmx_multi_world(const vmx_multi *m) { return m ? (uint32_t)m->replica.size() : 0u; }
+
+int vmx_multi_routes(const vmx_multi *m, int *devices, int *routes) {
+    if (!m) return fail(VMX_ERR_INVALID, "NULL argument");
+    for (size_t i = 0; i < m->replica.size(); ++i) {
+        if (devices) devices[i] = m->replica[i]->device;
+        if (routes) routes[i] = m->route[i];
+    }
+    return VMX_OK;
+}
 
 int vmx_multi_bind_texture(vmx_multi *m, const float *data, uint32_t width, uint32_t height, uint32_t channels) {
     if (!m) return fail(VMX_ERR_INVALID, "NULL argument");

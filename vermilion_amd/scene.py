@@ -220,6 +220,7 @@ class MultiScene:
         L.check(L.lib().vmx_multi_create(pos.ctypes.data, nrm.ctypes.data, uvp, pos.shape[0], sp, nsp, int(leaf_size),
                                          int(builder), devs, len(devices), C.byref(h)))
         self._h = h
+        self.ntris = pos.shape[0]
         self.world = L.lib().vmx_multi_world(h)
 
     def close(self):
@@ -238,6 +239,12 @@ class MultiScene:
 
     def __exit__(self, *a):
         self.close()
+
+    def routes(self):
+        """[(device, route)] per replica: route 2 = the root's own device, 1 = direct peer copy, 0 = staged through the host"""
+        d, r = (C.c_int * self.world)(), (C.c_int * self.world)()
+        L.check(L.lib().vmx_multi_routes(self._h, d, r))
+        return list(zip(list(d), list(r)))
 
     def bind_texture(self, data):
         data = np.ascontiguousarray(data, dtype=np.float32)
