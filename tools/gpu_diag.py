@@ -61,7 +61,7 @@ def check_scene(name, W, H, spp, nrays=200000):
     print("  primary_ids: id mismatches", int((tri != rtri).sum()), " t-bit mismatches", int((bits(t) != bits(rt)).sum()))
     # megakernel pipeline must give the same frame
     img1, st1 = sc.render(cam, va.make_opts(seed=9, early_stop=True))
-    for pl in (1, 2, 3, 4):
+    for pl in (1, 4):
         img2, st2 = sc.render(cam, va.make_opts(seed=9, early_stop=True, pipeline=pl))
         print(f"  pipeline={pl} vs 0 frame equal:", np.array_equal(bits(img1), bits(img2)), f" {st2['ms_device']:.1f} ms vs {st1['ms_device']:.1f} ms",
               "rays equal:", st1["rays_secondary"] == st2["rays_secondary"])

@@ -112,8 +112,8 @@ struct EventPool {
 
 // per-scene reusable device workspace for the render pipeline
 struct Workspace {
-    DevBuf<unsigned char> queue_planes[2];
-    DevBuf<unsigned int> queue_counts;  // 2 * kSubQueues * 32
+    DevBuf<unsigned char> queue_planes[2];  // first-generation kernels (A/B library) only
+    DevBuf<unsigned int> queue_counts;      // 2 * kSubQueues * 32
     DevBuf<unsigned int> heads;         // kSubQueues * 32 reservation heads of k_paths
     DevBuf<unsigned char> overflow_stack;  // k_paths: stack levels beyond the LDS part
     DevBuf<unsigned char> rayA, state, hit, thr;  // split wavefront: per-path state
@@ -298,6 +298,7 @@ int read_counts(vmx_scene *sc, unsigned int *d_counts, hipStream_t s, uint64_t &
     return VMX_OK;
 }
 
+#ifdef VMX_AB_KERNELS
 int run_queue(vmx_scene *sc, const FrameDev &fr, QueueDev q[2], int cur, void *rad, DevCounters *ctr, bool count,
               uint32_t tail_threshold, hipStream_t s, std::vector<TimedLaunch> &timed, uint64_t &launches,
               int bounce_blocks) {
@@ -325,6 +326,8 @@ int run_queue(vmx_scene *sc, const FrameDev &fr, QueueDev q[2], int cur, void *r
     }
     return VMX_OK;
 }
+
+#endif
 
 struct Tuning {
     uint32_t refill_min, refill_primary, shade_min, leaf_min, tail_threshold;
@@ -495,6 +498,7 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
     return VMX_OK;
 }
 
+#ifdef VMX_AB_KERNELS
 int ensure_queues(vmx_scene *sc, uint32_t sub_capacity, QueueDev q[2]) {
     Workspace &ws = sc->ws;
     const size_t cap = (size_t)sub_capacity * kSubQueues;
@@ -513,6 +517,8 @@ int ensure_queues(vmx_scene *sc, uint32_t sub_capacity, QueueDev q[2]) {
     }
     return VMX_OK;
 }
+
+#endif
 
 int finish_stats(vmx_scene *sc, hipStream_t s, std::vector<TimedLaunch> &timed, hipEvent_t ev0, hipEvent_t ev1,
                  vmx_stats *stats, uint64_t launches, uint64_t passes,
@@ -572,8 +578,13 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     //     kernel, which needs no per-generation host round trip)
     const uint32_t pipeline = opts->reserved[0];
     if (pipeline > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+#ifdef VMX_AB_KERNELS
     if (sc->dev.tex && pipeline >= 2 && pipeline <= 3)
         return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
+#else
+    if (pipeline >= 2 && pipeline <= 3)
+        return fail(VMX_ERR_INVALID, "pipeline forms 2 and 3 (first-generation kernels) are only in the A/B library (make ab)");
+#endif
     const bool split_any = pipeline == 0 || pipeline == 4;
     const bool legacy = pipeline >= 2 && pipeline <= 3;
     constexpr uint64_t kHybridPaths = 4ull << 20;  // measured: 1 M, 16 M and 64 M are all slower on early-stop frames
@@ -624,9 +635,10 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     const uint32_t smax_alloc = smax;  // buffers are sized for this many samples per pixel and pass
 
     int pb = 1, bb = 1;
-    const uint32_t lds = (sc->block / 64) * sc->dev.stack_entries * 512;
     int rb = 1;
-    HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, lds, count, &pb, &bb));
+#ifdef VMX_AB_KERNELS
+    HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, (sc->block / 64) * sc->dev.stack_entries * 512, count, &pb, &bb));
+#endif
     HIP_TRY((hipError_t)query_paths_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_entries + 1) * 512, count, &rb));
     if (pb < 1 || bb < 1 || rb < 1) return fail(VMX_ERR_HIP, "kernel does not fit on a CU (LDS stack too deep?)");
 
@@ -637,7 +649,9 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     // per sub-queue, overflow falls through to the next sub-queue and is reported if nothing fits
     uint32_t sub_cap = ((tiles8_max * smax) / kSubQueues + 2) * sc->block;
     sub_cap = sub_cap + sub_cap / 4 + 4096;
+#ifdef VMX_AB_KERNELS
     QueueDev q[2];
+#endif
     PathArrays pa{};
     IdQueue qi[2];
     int tb = 1, tbb = 1;  // blocks per CU of the trace kernel: camera rays, bounce rays
@@ -650,10 +664,15 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_primary + 1) * 512, count, &tb));
         HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, &tbb));
         if (tb < 1 || tbb < 1) return fail(VMX_ERR_HIP, "trace kernel does not fit on a CU");
-    } else if (legacy) {
+    }
+#ifdef VMX_AB_KERNELS
+    else if (legacy) {
         rc = ensure_queues(sc, sub_cap, q);
         if (rc) return rc;
     }
+#else
+    (void)sub_cap, (void)pb, (void)bb;
+#endif
     if (ws.heads.ensure(kSubQueues * 32)) return fail(VMX_ERR_NOMEM, "work heads");
     if (ws.rad.ensure((size_t)n_pad_max * smax * 16) || ws.accum.ensure((size_t)npix * 16) ||
         ws.count.ensure(npix) || ws.cursor.ensure(npix) || ws.active[0].ensure(npix) ||
@@ -738,7 +757,10 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         const bool split = pipeline == 4 || (pipeline == 0 && (uint64_t)n_pad * S >= kHybridPaths);
         const bool refill = pipeline == 1 || (pipeline == 0 && !split);
         const bool mega = refill || pipeline == 3;
+        (void)mega;
+#ifdef VMX_AB_KERNELS
         if (!mega && !split) HIP_TRY(hipMemsetAsync(q[0].counts, 0, kSubQueues * 32 * 4, s));
+#endif
         TimedLaunch tl{ws.events.get(), ws.events.get(), 0, VMX_K_OTHER};
         if (!tl.a || !tl.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         if (split) {
@@ -793,25 +815,35 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             if (rc) return rc;
             HIP_TRY(hipMemsetAsync(ws.heads.p, 0, kSubQueues * 32 * 4, s));
             HIP_TRY(hipEventRecord(tl.a, s));
-            LAUNCH_TRY(launch_paths(sc->dev, fr, wk, px, q[0], ws.rad.p, ws.counters.p, count, false, mega, cfg, s));
+            LAUNCH_TRY(launch_paths(sc->dev, fr, wk, px, ws.rad.p, ws.counters.p, count, cfg, s));
             HIP_TRY(hipEventRecord(tl.b, s));
-        } else {
+        }
+#ifdef VMX_AB_KERNELS
+        else {
             LaunchCfg cfg = trace_cfg(sc, tiles8 * S, pb);
             HIP_TRY(hipEventRecord(tl.a, s));
             LAUNCH_TRY(launch_primary(sc->dev, fr, ws.active[cur_list].p, n_active, S, px, q[0], ws.rad.p,
                                       ws.counters.p, count, mega, cfg, s));
             HIP_TRY(hipEventRecord(tl.b, s));
         }
+#else
+        (void)tiles8;
+#endif
         timed.push_back(tl);
         launches += 2;
         if (split) {
             rc = run_ids(sc, fr, pa, qi, 0, ws.counters.p, count, tn, s, timed, launches, tbb, rb);
             if (rc) return rc;
-        } else if (!mega) {
+        }
+#ifdef VMX_AB_KERNELS
+        else if (!mega) {
             rc = run_queue(sc, fr, q, 0, ws.rad.p, ws.counters.p, count, tail_threshold, s, timed, launches,
                            bb);
             if (rc) return rc;
         }
+#else
+        (void)tail_threshold;
+#endif
         HIP_TRY(hipMemsetAsync(ws.next_count.p, 0, 8, s));
         TimedLaunch tr{ws.events.get(), ws.events.get(), -1, VMX_K_RESOLVE};
         if (!tr.a || !tr.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
@@ -1158,8 +1190,13 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
         (opts->sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE)))
         return fail(VMX_ERR_INVALID, "unknown sampling mode");
     if (opts->reserved[0] > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+#ifdef VMX_AB_KERNELS
     if (sc->dev.tex && opts->reserved[0] >= 2 && opts->reserved[0] <= 3)
         return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
+#else
+    if (opts->reserved[0] >= 2 && opts->reserved[0] <= 3)
+        return fail(VMX_ERR_INVALID, "pipeline forms 2 and 3 (first-generation kernels) are only in the A/B library (make ab)");
+#endif
     if (n == 0) return VMX_OK;
     const auto t0 = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> lock(sc->mu);
@@ -1169,25 +1206,29 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     hipStream_t s = sc->stream;
     const bool count = opts->collect_counters != 0;
     const bool legacy = opts->reserved[0] == 2 || opts->reserved[0] == 3;  // first-generation kernels
+    (void)legacy;
     const Tuning tn = make_tuning(sc, opts);
     FrameDev fr;
     std::memset(&fr, 0, sizeof(fr));
     fr.r2scale = (opts->sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
     fr.libm_double = (opts->sampling & VMX_SAMPLING_LIBM_DOUBLE) ? 1u : 0u;
-    QueueDev q[2];
     PathArrays pa{};
     IdQueue qi[2];
-    int bb = 1, pb = 1, tb = 1, rb = 1;
-    const uint32_t lds_full = (sc->block / 64) * sc->dev.stack_entries * 512;
+    int tb = 1, rb = 1;
     const uint32_t lds_paths = (kPathsBlock / 64) * (tn.lds_entries + 1) * 512;
+#ifdef VMX_AB_KERNELS
+    QueueDev q[2];
+    int bb = 1, pb = 1;
     if (legacy) {
         const uint32_t blocks = (n + 255) / 256;
         const uint32_t sub_cap0 = (blocks / kSubQueues + 2) * 256;
         rc = ensure_queues(sc, sub_cap0 + sub_cap0 / 4 + 4096, q);
         if (rc) return rc;
         if (ws.rad.ensure((size_t)n * 16) || ws.counters.ensure(1)) return fail(VMX_ERR_NOMEM, "hipMalloc failed");
-        HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, lds_full, count, &pb, &bb));
-    } else {
+        HIP_TRY((hipError_t)query_blocks_per_cu(sc->block, (sc->block / 64) * sc->dev.stack_entries * 512, count, &pb, &bb));
+    } else
+#endif
+    {
         rc = ensure_paths(sc, n, pa, qi);
         if (rc) return rc;
         HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, &tb));
@@ -1205,12 +1246,15 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
         HIP_TRY(hipEventRecord(ev0, s));
         HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
         int r;
+#ifdef VMX_AB_KERNELS
         if (legacy) {
             HIP_TRY(hipMemsetAsync(q[0].counts, 0, kSubQueues * 32 * 4, s));
             LAUNCH_TRY(launch_radiance_init(d_o.p, d_d.p, n, opts->seed, q[0], s));
             launches += 2;
             r = run_queue(sc, fr, q, 0, ws.rad.p, ws.counters.p, count, tn.tail_threshold, s, timed, launches, bb);
-        } else {
+        } else
+#endif
+        {
             HIP_TRY(hipMemsetAsync(qi[0].counts, 0, kSubQueues * 32 * 4, s));
             LAUNCH_TRY(launch_radiance_init_ids(d_o.p, d_d.p, n, opts->seed, pa, qi[0], s));
             launches += 2;

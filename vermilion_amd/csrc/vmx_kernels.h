@@ -8,7 +8,7 @@ namespace vmx {
 
 constexpr uint32_t kSubQueues = 16;  // path sub-queues (one tail counter each, own cache line)
 
-struct QueueDev {
+struct QueueDev {  // first-generation kernels only (vmx_kernels_ab.inc): queue of 96-byte path records
     void *planes;             // float4[kPathPlanes][capacity]
     unsigned int *counts;     // [kSubQueues * 32] — counter q at counts[q*32] (128-byte spacing)
     uint32_t capacity;        // total slots = kSubQueues * sub_capacity
@@ -60,8 +60,7 @@ struct WorkDev {
     uint32_t band_items;        // band_slots * samples
     uint32_t pixel_major;       // 1: pid = slot * samples + j (samples of a pixel contiguous); 0: j * n_pad + slot
     // queue source
-    QueueDev qin;     // first-generation kernels (96-byte path records)
-    IdQueue qids;     // k_trace_q / k_shade / tail (path ids)
+    IdQueue qids;     // k_trace_w / k_trace_q / k_shade / tail (path ids)
     // camera rays: per-frame origin-relative node / triangle tables (k_camera_tables)
     const void *cam_inner;  // float4[8 * n_inner * 4]: one copy per direction octant, octant 0 = plain (lo, hi)
     uint32_t cam_n_inner;   // records per copy
@@ -87,6 +86,7 @@ int launch_trig(const float *x, uint32_t n, float *cs, float *sn, void *stream);
 // ---- render pipeline -----------------------------------------------------------
 int launch_init_pixels(PixelStateDev px, uint32_t npix, void *stream);
 int launch_zero_u32(unsigned int *p, uint32_t n, void *stream);
+#ifdef VMX_AB_KERNELS  // first-generation kernels (vmx_kernels_ab.inc), A/B library only
 // raygen + trace + shade for `samples` samples of each of n_active pixels.
 // loop_to_end: every lane follows its path to termination (megakernel form).
 int launch_primary(const SceneDev &sc, const FrameDev &fr, const unsigned int *active,
@@ -99,11 +99,12 @@ int launch_radiance_init(const float *o, const float *d, uint32_t n, uint64_t se
 int launch_bounce(const SceneDev &sc, float r2scale, uint32_t libm_double, QueueDev qin, uint32_t max_chunks, QueueDev qout,
                   void *rad, DevCounters *counters, bool count, bool loop_to_end, bool first_step,
                   LaunchCfg cfg, void *stream);
+int query_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *primary_blocks, int *bounce_blocks);
+#endif
 // per-pixel accumulation in sample order, early-stop rule, pixel write, next active list
-// persistent kernel with per-lane refill: primary (ray generation) or queue source
-int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, QueueDev qout,
-                 void *rad, DevCounters *counters, bool count, bool from_queue, bool loop_to_end, LaunchCfg cfg,
-                 void *stream);
+// persistent fused kernel with per-lane refill (ray generation source): every lane keeps its path to the end
+int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, void *rad,
+                 DevCounters *counters, bool count, LaunchCfg cfg, void *stream);
 int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks);
 // split wavefront: persistent trace kernel (per-lane refill) ...
 int launch_camera_tables(const SceneDev &sc, uint32_t n_inner, float ox, float oy, float oz, void *cam_inner,
@@ -148,9 +149,5 @@ size_t path_sort_tmp_bytes(uint32_t max_n);
 int path_sort_ids(const IdQueue &q, const uint32_t *h_counts, const void *state, const SortKeyCfg &cfg,
                   unsigned int *keys_a, unsigned int *keys_b, unsigned int *ids_out, void *tmp, size_t tmp_bytes,
                   void *stream);
-
-// occupancy helpers (host): blocks per CU for the trace-heavy kernels at this LDS size
-int query_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *primary_blocks,
-                        int *bounce_blocks);
 
 }  // namespace vmx

@@ -8,10 +8,13 @@
 // Kernels
 //   k_trace        BVH::getIntersection for explicit rays          (bvh.cpp:47-145)
 //   k_raycast      MeshEngine::RayCast for explicit rays           (meshEngine.cpp:239-509)
-//   k_primary      ray generation + RayCast + Radiance step at depth 0, path compaction
-//                                                                   (pathtracer.cpp:251-280, 36-196)
-//   k_bounce       RayCast + Radiance step for queued paths, path compaction
+//   k_raygen       camera rays of a pass                           (pathtracer.cpp:251-280)
+//   k_trace_w      persistent BVH traversal of camera / bounce rays (bvh.cpp:47-145); k_trace_q: counting form
+//   k_shade        RayCast tail + one Radiance step, id compaction  (meshEngine.cpp:365-508, pathtracer.cpp:36-196)
+//   k_paths        traversal + shading fused, paths kept to their end (small passes, the tail of a pass)
 //   k_resolve      per-pixel accumulation, early stop, pixel write (pathtracer.cpp:282-324)
+//   k_bruteforce*  BruteForceTracer::Render                        (integrators.cpp:9-186)
+// (the first-generation kernels k_primary / k_bounce live in vmx_kernels_ab.inc: A/B library only)
 //
 // Execution model: persistent blocks stride over block-sized work items; the
 // item -> image-region map is XCD-aware (items b and b+8 run on one XCD and
@@ -715,87 +718,6 @@ __device__ __forceinline__ bool path_shade(const SceneDev &sc, SampCfg cfg, Path
     return path_shade_end(P, c, fl, m, cs, sn);
 }
 
-template <bool COUNT>
-__device__ __forceinline__ bool path_step(const SceneDev &sc, SampCfg cfg, Path &P, uint2 *stk,
-                                          StepFlags &fl, Cnt &cnt) {
-    CastResult c;
-    ray_cast<COUNT>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, stk, c, cnt);
-    return path_shade<false>(sc, cfg, P, c, fl);
-}
-
-// ---------------------------------------------------------------------------
-// path queue (SoA of float4 planes, 16 sub-queues)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void path_store(const QueueDev &q, uint32_t idx, const Path &P) {
-    float4 *pl = (float4 *)q.planes;
-    const size_t cap = q.capacity;
-    pl[idx] = make_float4(P.ox, P.oy, P.oz, P.dx);
-    pl[cap + idx] = make_float4(P.dy, P.dz, 1.f, 1.f);
-    pl[2 * cap + idx] = make_float4(1.f, P.ar, P.ag, P.ab);
-    pl[3 * cap + idx] = make_float4(P.aw, __uint_as_float(P.depth), __uint_as_float(P.dest), 0.f);
-    pl[4 * cap + idx] = make_float4(__uint_as_float((uint32_t)P.rng.s0), __uint_as_float((uint32_t)(P.rng.s0 >> 32)),
-                                    __uint_as_float((uint32_t)P.rng.s1), __uint_as_float((uint32_t)(P.rng.s1 >> 32)));
-    pl[5 * cap + idx] = make_float4(__uint_as_float((uint32_t)P.rng.s2), __uint_as_float((uint32_t)(P.rng.s2 >> 32)),
-                                    __uint_as_float((uint32_t)P.rng.s3), __uint_as_float((uint32_t)(P.rng.s3 >> 32)));
-}
-
-__device__ __forceinline__ void path_load(const QueueDev &q, uint32_t idx, Path &P) {
-    const float4 *pl = (const float4 *)q.planes;
-    const size_t cap = q.capacity;
-    const float4 a = pl[idx], b = pl[cap + idx], c = pl[2 * cap + idx], d = pl[3 * cap + idx],
-                 e = pl[4 * cap + idx], f = pl[5 * cap + idx];
-    P.ox = a.x, P.oy = a.y, P.oz = a.z, P.dx = a.w;
-    P.dy = b.x, P.dz = b.y;
-    P.ar = c.y, P.ag = c.z, P.ab = c.w;
-    P.aw = d.x, P.depth = __float_as_uint(d.y), P.dest = __float_as_uint(d.z);
-    P.rng.s0 = (uint64_t)__float_as_uint(e.x) | ((uint64_t)__float_as_uint(e.y) << 32);
-    P.rng.s1 = (uint64_t)__float_as_uint(e.z) | ((uint64_t)__float_as_uint(e.w) << 32);
-    P.rng.s2 = (uint64_t)__float_as_uint(f.x) | ((uint64_t)__float_as_uint(f.y) << 32);
-    P.rng.s3 = (uint64_t)__float_as_uint(f.z) | ((uint64_t)__float_as_uint(f.w) << 32);
-}
-
-// wave ballot + prefix popcount compaction, one atomic per wave
-__device__ __forceinline__ void queue_append(const QueueDev &q, uint32_t sub, bool alive, const Path &P) {
-    const unsigned long long m = __ballot(alive);
-    if (m == 0) return;
-    const uint32_t n = (uint32_t)__popcll(m);
-    const uint32_t lane = lane_index();
-    uint32_t base = 0;
-    if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(&q.counts[sub * 32], n);
-    base = __shfl(base, __ffsll((long long)m) - 1, 64);
-    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (alive) path_store(q, sub * q.sub_capacity + base + rank, P);
-}
-
-// same, with an overflow check: a full sub-queue makes the wave try the next one
-// (its tail stays over-incremented; consumers clamp counts to sub_capacity).
-// Returns false if no sub-queue could take the wave's paths (host reports an error).
-__device__ __forceinline__ bool queue_append_checked(const QueueDev &q, uint32_t sub, bool alive, const Path &P) {
-    const unsigned long long m = __ballot(alive);
-    if (m == 0) return true;
-    const uint32_t n = (uint32_t)__popcll(m);
-    const uint32_t lane = lane_index();
-    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (uint32_t attempt = 0; attempt < kSubQueues; ++attempt) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&q.counts[sub * 32], n);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base + n <= q.sub_capacity) {
-            if (alive) path_store(q, sub * q.sub_capacity + base + rank, P);
-            return true;
-        }
-        if (base < q.sub_capacity) {
-            // partial room: the slots [base, cap) stay unwritten; mark them dead (depth = ~0)
-            float4 *pl = (float4 *)q.planes;
-            const uint32_t room = q.sub_capacity - base;
-            if (lane < room) pl[3 * (size_t)q.capacity + sub * q.sub_capacity + base + lane] =
-                make_float4(0.f, __uint_as_float(0xFFFFFFFFu), 0.f, 0.f);
-        }
-        sub = (sub + 1 == kSubQueues) ? 0 : sub + 1;
-    }
-    return false;
-}
-
 __device__ __forceinline__ void tally_add(Tally &tl, const StepFlags &fl, bool ran, uint32_t stage_depth0) {
     // stage 0 = steps taken at depth 0, stage 1 = bounce steps
     const unsigned long long r0 = __ballot(ran && fl.was_ray && stage_depth0);
@@ -950,14 +872,6 @@ __device__ __forceinline__ bool primary_item(const FrameDev &fr, const WorkDev &
     return true;
 }
 
-// block-sized work item -> (sample plane j, first slot), XCD-aware:
-// items i and i+8 land on one XCD (round-robin block placement) and get neighbouring tiles
-__device__ __forceinline__ void item_to_tile(uint32_t item, uint32_t tiles8, uint32_t &j, uint32_t &tile) {
-    const uint32_t xcd = item & 7u, r = item >> 3, per = tiles8 >> 3;
-    j = r / per;
-    tile = xcd * per + (r - j * per);
-}
-
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
@@ -1051,137 +965,6 @@ __global__ void k_zero_u32(unsigned int *p, uint32_t n) {
     if (i < n) p[i] = 0;
 }
 
-// raygen + RayCast + first Radiance step; LOOP: follow every path to its end
-template <bool COUNT, bool LOOP>
-__global__ void k_primary(SceneDev sc, FrameDev fr, const unsigned int *__restrict__ active, uint32_t n_active,
-                          uint32_t n_pad, uint32_t samples, PixelStateDev px, QueueDev qout,
-                          float4 *__restrict__ rad, DevCounters *ctr) {
-    extern __shared__ uint2 lds_stack[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
-    const uint32_t tiles = (n_pad + blockDim.x - 1) / blockDim.x;
-    const uint32_t tiles8 = (tiles + 7u) & ~7u;
-    const uint32_t items = tiles8 * samples;
-    Cnt c0 = {0, 0}, c1 = {0, 0};
-    Tally tl = {{0, 0}, {0, 0}, {0, 0}};
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-        uint32_t j, tile;
-        item_to_tile(item, tiles8, j, tile);
-        const uint32_t slot = tile * blockDim.x + threadIdx.x;
-        bool run = slot < n_active;
-        Path P;
-        uint32_t lp = 0;
-        if (run) {
-            lp = active[slot];
-            const uint32_t k = sample_index(fr, px, lp, j);
-            run = k < fr.kmax;
-            if (run) {
-                const uint32_t p = global_pixel(fr, lp);
-                primary_ray(fr, p, k, P.rng, P.dx, P.dy, P.dz);
-                P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz;
-                P.ar = P.ag = P.ab = 0.f;
-                P.aw = -100.f;  // pathtracer.cpp:29
-                P.depth = 0;
-                P.dest = j * n_pad + slot;
-            }
-        }
-        StepFlags fl = {false, false, false};
-        bool alive = false;
-        if (run) {
-            fl.was_ray = true;
-            alive = path_step<COUNT>(sc, SampCfg{fr.r2scale, fr.libm_double}, P, stk, fl, c0);
-        }
-        tally_add(tl, fl, run, 1u);
-        if (LOOP) {
-            while (__any(alive)) {
-                StepFlags f2 = {false, false, false};
-                bool still = false;
-                if (alive) {
-                    f2.was_ray = finite3(P.dx, P.dy, P.dz);
-                    still = path_step<COUNT>(sc, SampCfg{fr.r2scale, fr.libm_double}, P, stk, f2, c1);
-                }
-                tally_add(tl, f2, alive, 0u);
-                alive = still;
-            }
-            if (run) rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
-        } else {
-            if (run && !alive) rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
-            queue_append(qout, item % kSubQueues, alive, P);
-        }
-    }
-    tally_flush<COUNT>(ctr, tl, c0, c1);
-}
-
-// explicit camera rays for vmx_radiance: path i keyed (seed, i, 0), two jitter draws skipped
-__global__ void k_radiance_init(const float *__restrict__ o, const float *__restrict__ d, uint32_t n,
-                                uint64_t seed, QueueDev qout) {
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + threadIdx.x;
-        const bool run = i < n;
-        Path P;
-        if (run) {
-            rng_init(P.rng, seed, i, 0);
-            (void)rng_next(P.rng);
-            (void)rng_next(P.rng);
-            P.ox = o[i * 3], P.oy = o[i * 3 + 1], P.oz = o[i * 3 + 2];
-            P.dx = d[i * 3], P.dy = d[i * 3 + 1], P.dz = d[i * 3 + 2];
-            P.ar = P.ag = P.ab = 0.f;
-            P.aw = -100.f;
-            P.depth = 0;
-            P.dest = i;
-        }
-        queue_append(qout, (base / blockDim.x) % kSubQueues, run, P);
-    }
-}
-
-// one Radiance step (LOOP: all remaining steps) for every queued path
-template <bool COUNT, bool LOOP>
-__global__ void k_bounce(SceneDev sc, SampCfg r2scale, QueueDev qin, uint32_t max_chunks, QueueDev qout,
-                         float4 *__restrict__ rad, DevCounters *ctr) {
-    extern __shared__ uint2 lds_stack[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2 *stk = lds_stack + (size_t)wave * sc.stack_entries * 64 + lane;
-    const uint32_t items = max_chunks * kSubQueues;
-    Cnt c0 = {0, 0}, c1 = {0, 0};
-    Tally tl = {{0, 0}, {0, 0}, {0, 0}};
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
-        const uint32_t count = qin.counts[sub * 32];
-        const uint32_t pos = chunk * blockDim.x + threadIdx.x;
-        const bool run = pos < count;
-        Path P;
-        StepFlags fl = {false, false, false};
-        bool alive = false;
-        uint32_t depth0 = 0;
-        if (run) {
-            path_load(qin, sub * qin.sub_capacity + pos, P);
-            depth0 = P.depth == 0 ? 1u : 0u;
-            fl.was_ray = depth0 ? true : finite3(P.dx, P.dy, P.dz);
-            alive = depth0 ? path_step<COUNT>(sc, r2scale, P, stk, fl, c0)
-                           : path_step<COUNT>(sc, r2scale, P, stk, fl, c1);
-        }
-        tally_add(tl, fl, run, depth0);
-        if (LOOP) {
-            while (__any(alive)) {
-                StepFlags f2 = {false, false, false};
-                bool still = false;
-                if (alive) {
-                    f2.was_ray = finite3(P.dx, P.dy, P.dz);
-                    still = path_step<COUNT>(sc, r2scale, P, stk, f2, c1);
-                }
-                tally_add(tl, f2, alive, 0u);
-                alive = still;
-            }
-            if (run) rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
-        } else {
-            if (run && !alive) rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
-            queue_append(qout, sub, alive, P);
-        }
-    }
-    tally_flush<COUNT>(ctr, tl, c0, c1);
-}
-
-
 // ---------------------------------------------------------------------------
 // quad-cooperative record fetch (k_trace_w<1>, k_paths).  A 64-byte record read by ONE lane as four 16-byte
 // loads costs four tag lookups in the vector L1; read by the four lanes of a quad — lane j takes
@@ -1252,7 +1035,7 @@ __device__ __forceinline__ void quad_fetch_record(const char *base, uint32_t off
 //   SRC 0: work = (sample j, slot) pairs of the active-pixel list, in 8 bands
 //          of neighbouring tiles (band = block % 8 = XCD label; exhausted
 //          bands are stolen from), paths start with ray generation
-//   SRC 1: work = the 16 sub-queues of a path queue
+//   SRC 2: work = the 16 sub-queues of live path ids (the tail of a pass)
 // ---------------------------------------------------------------------------
 // LDS holds levels [0, lds_entries) plus one scratch entry at index lds_entries; deeper levels
 // (rare) go to the per-wave global slab.  The LDS access is unconditional on a clamped index so
@@ -1273,10 +1056,10 @@ __device__ __forceinline__ uint2 stack_pop(const uint2 *stk, const uint2 *ovf, i
 #ifndef VMX_PATHS_WPS
 #define VMX_PATHS_WPS 6  // waves per SIMD the fused kernel is compiled for (80 VGPRs): tail 8.8 -> 7.9 ms, early-stop frame 14.3 -> 13.8 ms (5: 8.1, 7: 8.4, 8: 8.9)
 #endif
-template <bool COUNT, int SRC, bool LOOP, bool TEX>
+template <bool COUNT, int SRC, bool TEX>
 __global__ void __launch_bounds__(256, VMX_PATHS_WPS)
-k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, float4 *__restrict__ rad,
-        PathArrays pa, DevCounters *ctr) {
+k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, float4 *__restrict__ rad, PathArrays pa,
+        DevCounters *ctr) {
     extern __shared__ uint2 lds_stack[];
     __shared__ float4 s_geom[kLdsSpheres];  // spheres' (centre, rad*rad): read by every RayCast
     if (threadIdx.x < min(sc.nspheres, kLdsSpheres)) {
@@ -1297,7 +1080,6 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
     // wave-uniform scheduling state
     uint32_t src = blockIdx.x % wk.nsrc, res_lo = 0, res_hi = 0, tried = 0;
     bool exhausted = false;
-    const uint32_t out_sub = blockIdx.x % kSubQueues;
     // lane state
     // traversal state as in k_trace_w: `cur` = node reference, kIdle while the lane is not traversing
     // (no path, or traversal finished and the path waits for shading); stack level 0 = bottom entry
@@ -1310,7 +1092,6 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
     stk[0] = make_uint2(kBottom, 0xFF800000u);
     Cnt c0 = {0, 0}, c1 = {0, 0};
     Tally tl = {{0, 0}, {0, 0}, {0, 0}};
-    uint32_t overflow = 0;
 
     auto start_traversal = [&]() {
         ix = 1.0f / P.dx, iy = 1.0f / P.dy, iz = 1.0f / P.dz;  // Ray.h:10
@@ -1344,12 +1125,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                     }
                 }
                 tally_add(tl, fl, shaded, depth0);
-                if (LOOP) {
-                    if (shaded && alive) start_traversal();
-                } else {
-                    if (!queue_append_checked(qout, out_sub, alive, P)) overflow = 1;
-                    if (shaded && alive) has = false;
-                }
+                if (shaded && alive) start_traversal();  // the lane keeps its path to the end
             }
         }
         // ---- 2. refill idle lanes from the work source ---------------------------
@@ -1358,9 +1134,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
             if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= wk.refill_min || idle == ~0ull)) {
                 for (;;) {
                     if (res_lo == res_hi) {
-                        const uint32_t lim = SRC == 0   ? wk.band_items
-                                             : SRC == 1 ? min(wk.qin.counts[src * 32], wk.qin.sub_capacity)
-                                                        : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
+                        const uint32_t lim = SRC == 0 ? wk.band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
                         uint32_t base = 0;
                         if (lane == 0) base = atomicAdd(&wk.heads[src * 32], kReserve);
                         base = __builtin_amdgcn_readfirstlane(base);
@@ -1408,9 +1182,6 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
                                     P.dest = path_id(wk, j, s_idx);
                                 }
                             }
-                        } else if (SRC == 1) {
-                            path_load(wk.qin, src * wk.qin.sub_capacity + item, P);
-                            valid = P.depth != 0xFFFFFFFFu;  // dead slot left by an overflowing append
                         } else {
                             path_load_arrays<TEX>(pa, wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item], P);
                         }
@@ -1513,7 +1284,6 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, QueueDev qout, f
         }
     }
     tally_flush<COUNT>(ctr, tl, c0, c1);
-    if (__ballot(overflow != 0) != 0 && lane == 0) atomicAdd(&ctr->overflow, 1ull);
 }
 
 
@@ -1975,45 +1745,7 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
 }
 
 #ifdef VMX_STEP_PROFILE
-// Diagnostic build only (tools/step_profile.py; make EXTRA=-DVMX_STEP_PROFILE): wave-cycles and wave-steps of
-// k_trace_w by the state in which the wave enters a step.  [SRC][category][0 = cycles, 1 = steps]; categories:
-// 0 every traversing lane at the same inner node, 1 inner nodes only (not all the same), 2 leaves only,
-// 3 inner nodes and leaves, 4 no traversing lane, 5 refill section, 6 steps of NaN-exact batches and same-inner-node steps of waves whose rays do not share an octant,
-// 7 nodes done by uniform_descent, 8 its entries (count; "cycles" = traversing lanes at entry, summed)
-__device__ unsigned long long g_step_prof[2][10][2];
-// per launch kind: [0] earliest wave start, [1] latest wave end, [2] sum of wave ends, [3] waves (100 MHz wall clock)
-__device__ unsigned long long g_wave_span[2][4];
-extern "C" int vmx_debug_wave_span(unsigned long long *out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_span), sizeof(g_wave_span)) != hipSuccess) return -1;
-    if (reset) {
-        static unsigned long long init[2][4] = {{~0ull, 0, 0, 0}, {~0ull, 0, 0, 0}};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_wave_span), init, sizeof(init)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-extern "C" int vmx_debug_step_profile(unsigned long long *out, int reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_prof), sizeof(g_step_prof)) != hipSuccess) return -1;
-    if (reset) {
-        static unsigned long long zero[2][10][2];
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_step_prof), zero, sizeof(zero)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#define VMX_PROF_STEP(EX, OC)                                                                                   \
-    do {                                                                                                        \
-        const unsigned long long pt_ = __builtin_amdgcn_ballot_w64(cur != kIdle);                               \
-        const unsigned long long pl_ = __builtin_amdgcn_ballot_w64(cur != kIdle && (int)cur < 0);               \
-        const uint32_t pc0_ = (uint32_t)__builtin_amdgcn_readlane((int)cur, pt_ ? (int)__ffsll((long long)pt_) - 1 : 0); \
-        const bool pu_ = __builtin_amdgcn_ballot_w64(cur != kIdle && cur != pc0_) == 0;                         \
-        const uint32_t cat_ = decltype(EX)::value ? 6u : pt_ == 0 ? 4u : pl_ == pt_ ? 2u : pl_ != 0 ? 3u : !pu_ ? 1u : decltype(OC)::value ? 0u : 6u; \
-        const unsigned long long t0_ = __builtin_readcyclecounter();                                            \
-        step(EX, OC);                                                                                           \
-        const unsigned long long t1_ = __builtin_readcyclecounter();                                            \
-        if (lane == 0) {                                                                                        \
-            s_prof[wave][cat_][0] += t1_ - t0_;                                                                 \
-            s_prof[wave][cat_][1] += 1;                                                                         \
-        }                                                                                                       \
-    } while (0)
+#include "vmx_step_profile.inc"
 #else
 #define VMX_PROF_STEP(EX, OC) step(EX, OC)
 #endif
@@ -2921,69 +2653,19 @@ int launch_zero_u32(unsigned int *p, uint32_t n, void *stream) {
     return launch_status();
 }
 
-int launch_primary(const SceneDev &sc, const FrameDev &fr, const unsigned int *active, uint32_t n_active,
-                   uint32_t samples, PixelStateDev px, QueueDev qout, void *rad, DevCounters *counters, bool count,
-                   bool loop_to_end, LaunchCfg cfg, void *stream) {
-    const uint32_t n_pad = (n_active + 63u) & ~63u;
+int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, void *rad,
+                 DevCounters *counters, bool count, LaunchCfg cfg, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     dim3 g(cfg.grid), b(cfg.block);
-#define VMX_GO(C, L)                                                                                              \
-    hipLaunchKernelGGL((k_primary<C, L>), g, b, cfg.lds_bytes, s, sc, fr, active, n_active, n_pad, samples, px, \
-                       qout, (float4 *)rad, counters)
-    if (count) {
-        if (loop_to_end) VMX_GO(true, true);
-        else VMX_GO(true, false);
-    } else {
-        if (loop_to_end) VMX_GO(false, true);
-        else VMX_GO(false, false);
-    }
-#undef VMX_GO
-    return launch_status();
-}
-
-int launch_radiance_init(const float *o, const float *d, uint32_t n, uint64_t seed, QueueDev qout, void *stream) {
-    uint32_t grid = (n + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_radiance_init, dim3(grid), dim3(256), 0, (hipStream_t)stream, o, d, n, seed, qout);
-    return launch_status();
-}
-
-int launch_bounce(const SceneDev &sc, float r2scale_f, uint32_t libm_double, QueueDev qin, uint32_t max_chunks, QueueDev qout,
-                  void *rad, DevCounters *counters, bool count, bool loop_to_end, bool, LaunchCfg cfg, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    dim3 g(cfg.grid), b(cfg.block);
-    const SampCfg r2scale{r2scale_f, libm_double};
-#define VMX_GO(C, L)                                                                                       \
-    hipLaunchKernelGGL((k_bounce<C, L>), g, b, cfg.lds_bytes, s, sc, r2scale, qin, max_chunks, qout,      \
-                       (float4 *)rad, counters)
-    if (count) {
-        if (loop_to_end) VMX_GO(true, true);
-        else VMX_GO(true, false);
-    } else {
-        if (loop_to_end) VMX_GO(false, true);
-        else VMX_GO(false, false);
-    }
-#undef VMX_GO
-    return launch_status();
-}
-
-int launch_paths(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, QueueDev qout,
-                 void *rad, DevCounters *counters, bool count, bool from_queue, bool loop_to_end, LaunchCfg cfg,
-                 void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    dim3 g(cfg.grid), b(cfg.block);
-#define VMX_GO(C, S, L, T)                                                                                   \
-    hipLaunchKernelGGL((k_paths<C, S, L, T>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)rad, pa, counters)
-    // instantiated forms: primary source following every path to its end (pipeline 1)
+#define VMX_GO(C, T) \
+    hipLaunchKernelGGL((k_paths<C, 0, T>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, (float4 *)rad, pa, counters)
     PathArrays pa{};
-    (void)from_queue;
-    (void)loop_to_end;
     if (sc.tex) {
-        if (count) VMX_GO(true, 0, true, true);
-        else VMX_GO(false, 0, true, true);
+        if (count) VMX_GO(true, true);
+        else VMX_GO(false, true);
     } else {
-        if (count) VMX_GO(true, 0, true, false);
-        else VMX_GO(false, 0, true, false);
+        if (count) VMX_GO(true, false);
+        else VMX_GO(false, false);
     }
 #undef VMX_GO
     return launch_status();
@@ -2994,9 +2676,8 @@ int launch_tail(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathA
     hipStream_t s = (hipStream_t)stream;
     dim3 g(cfg.grid), b(cfg.block);
     PixelStateDev px{nullptr, nullptr, nullptr};
-    QueueDev qout{};
 #define VMX_GO(C, T) \
-    hipLaunchKernelGGL((k_paths<C, 2, true, T>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, qout, (float4 *)pa.rad, pa, counters)
+    hipLaunchKernelGGL((k_paths<C, 2, T>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, (float4 *)pa.rad, pa, counters)
     if (sc.tex) {
         if (count) VMX_GO(true, true);
         else VMX_GO(false, true);
@@ -3087,11 +2768,11 @@ int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, in
     int a = 0, b = 0;
     hipError_t e;
     if (count) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<true, 0, true, true>, (int)block, lds_bytes);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<true, 2, true, true>, (int)block, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<true, 0, true>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<true, 2, true>, (int)block, lds_bytes);
     } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<false, 0, true, true>, (int)block, lds_bytes);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<false, 2, true, true>, (int)block, lds_bytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_paths<false, 0, true>, (int)block, lds_bytes);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_paths<false, 2, true>, (int)block, lds_bytes);
     }
     if (blocks) *blocks = a < b ? a : b;
     return (int)e;
@@ -3140,21 +2821,9 @@ int launch_quantize(const float *frame, uint64_t npix, void *rgba8, float *depth
     return launch_status();
 }
 
-int query_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *primary_blocks, int *bounce_blocks) {
-    int a = 0, b = 0;
-    hipError_t e;
-    if (count) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_primary<true, false>, (int)block, lds_bytes);
-        if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_bounce<true, false>, (int)block, lds_bytes);
-    } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_primary<false, false>, (int)block, lds_bytes);
-        if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_bounce<false, false>, (int)block, lds_bytes);
-    }
-    if (primary_blocks) *primary_blocks = a;
-    if (bounce_blocks) *bounce_blocks = b;
-    return (int)e;
-}
+#ifdef VMX_AB_KERNELS
+// first-generation kernels (pipeline forms 2, 3): only in the A/B library of `make ab`, never in the product
+#include "vmx_kernels_ab.inc"
+#endif
 
 }  // namespace vmx

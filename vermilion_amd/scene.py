@@ -39,7 +39,7 @@ def make_opts(seed=1, early_stop=True, sampling=L.VMX_SAMPLING_PARITY, rank=0, w
     o.rank, o.world, o.stripe_rows = int(rank), int(world), int(stripe_rows)
     o.samples_per_batch = int(samples_per_batch)
     o.collect_counters = 1 if collect_counters else 0
-    o.reserved[0] = int(pipeline)      # 0/1 refill kernels (wavefront / to-the-end), 2/3 first-generation kernels
+    o.reserved[0] = int(pipeline)      # 0 default routing, 1 fused kernel for every pass, 4 split wavefront for every pass; 2/3 first-generation kernels (A/B library only)
     o.reserved[1] = int(max_paths)     # paths in flight per pass (0 -> 16M)
     o.reserved[2] = int(tail_threshold)
     o.reserved[3] = int(refill_min)    # k_paths: refill when this many lanes idle (0 -> 16)
@@ -74,7 +74,9 @@ def default_spheres():
 class Scene:
     """Device-resident scene: replaces MeshEngine::createBVH + BVH for the HIP path."""
 
-    def __init__(self, pos, nrm, uv=None, spheres=None, leaf_size=4, device=0, builder=L.VMX_BVH_REFERENCE):
+    def __init__(self, pos, nrm, uv=None, spheres=None, leaf_size=4, device=0, builder=L.VMX_BVH_REFERENCE, lib=None):
+        """lib: a library object from _lib.load(path) — the tests' A/B library; default: the product library"""
+        self._lib = lib if lib is not None else L.lib()
         pos = _f32(pos).reshape(-1, 9)
         nrm = _f32(nrm).reshape(-1, 9)
         if pos.shape != nrm.shape:
@@ -86,15 +88,19 @@ class Scene:
         self._spheres = spheres
         sp, nsp = (None, 0) if spheres is None else (C.addressof(spheres), len(spheres))
         h = C.c_void_p()
-        L.check(L.lib().vmx_scene_create_ex(pos.ctypes.data, nrm.ctypes.data, uvp, pos.shape[0], sp, nsp,
+        self._check(self._lib.vmx_scene_create_ex(pos.ctypes.data, nrm.ctypes.data, uvp, pos.shape[0], sp, nsp,
                                             int(leaf_size), int(builder), int(device), C.byref(h)))
         self._h = h
         self.ntris = pos.shape[0]
         self.device = int(device)
 
+    def _check(self, code):
+        if code != L.VMX_OK:
+            raise L.VmxError(code, self._lib.vmx_last_error().decode("utf-8", "replace"))
+
     def close(self):
         if getattr(self, "_h", None):
-            L.lib().vmx_scene_destroy(self._h)
+            self._lib.vmx_scene_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -116,19 +122,19 @@ class Scene:
         if data.ndim not in (2, 3):
             raise ValueError("texture must be [H, W] or [H, W, C]")
         c = 1 if data.ndim == 2 else data.shape[2]
-        L.check(L.lib().vmx_scene_bind_texture(self._h, data.ctypes.data, data.shape[1], data.shape[0], c))
+        self._check(self._lib.vmx_scene_bind_texture(self._h, data.ctypes.data, data.shape[1], data.shape[0], c))
         return True
 
     # -- introspection ----------------------------------------------------
     def describe(self):
         d = L.SceneDesc()
-        L.check(L.lib().vmx_scene_describe(self._h, C.byref(d)))
+        self._check(self._lib.vmx_scene_describe(self._h, C.byref(d)))
         return {k: getattr(d, k) for k, _ in d._fields_ if k != "pad"}
 
     def timings(self):
         """per-kernel device time of the last render on this scene (vmx_timings)"""
         t = L.Timings()
-        L.check(L.lib().vmx_scene_timings(self._h, C.byref(t)))
+        self._check(self._lib.vmx_scene_timings(self._h, C.byref(t)))
         return t.as_dict()
 
     def bvh(self):
@@ -138,7 +144,7 @@ class Scene:
         roff = np.zeros(n, np.uint32)
         bbox = np.zeros((n, 6), np.float32)
         order = np.zeros(self.ntris, np.uint32)
-        L.check(L.lib().vmx_scene_bvh(self._h, start.ctypes.data, nprims.ctypes.data, roff.ctypes.data,
+        self._check(self._lib.vmx_scene_bvh(self._h, start.ctypes.data, nprims.ctypes.data, roff.ctypes.data,
                                       bbox.ctypes.data, order.ctypes.data))
         return {"start": start, "nprims": nprims, "right_offset": roff, "bbox": bbox, "prim_order": order}
 
@@ -148,21 +154,21 @@ class Scene:
         n = o.shape[0]
         tri = np.empty(n, np.int32)
         t = np.empty(n, np.float32)
-        L.check(L.lib().vmx_trace(self._h, o.ctypes.data, d.ctypes.data, n, tri.ctypes.data, t.ctypes.data))
+        self._check(self._lib.vmx_trace(self._h, o.ctypes.data, d.ctypes.data, n, tri.ctypes.data, t.ctypes.data))
         return tri, t
 
     def raycast(self, origin, direction):
         o, d = _f32(origin, 3), _f32(direction, 3)
         n = o.shape[0]
         out = np.zeros(n, dtype=RAYHIT_DTYPE)
-        L.check(L.lib().vmx_raycast(self._h, o.ctypes.data, d.ctypes.data, n, out.ctypes.data))
+        self._check(self._lib.vmx_raycast(self._h, o.ctypes.data, d.ctypes.data, n, out.ctypes.data))
         return out
 
     def primary_ids(self, cam, opts, k=0):
         n = cam.image_res[0] * cam.image_res[1]
         tri = np.empty(n, np.int32)
         t = np.empty(n, np.float32)
-        L.check(L.lib().vmx_primary_ids(self._h, C.byref(cam), C.byref(opts), int(k), tri.ctypes.data,
+        self._check(self._lib.vmx_primary_ids(self._h, C.byref(cam), C.byref(opts), int(k), tri.ctypes.data,
                                         t.ctypes.data))
         return tri, t
 
@@ -171,7 +177,7 @@ class Scene:
         n = o.shape[0]
         out = np.empty((n, 4), np.float32)
         st = L.Stats()
-        L.check(L.lib().vmx_radiance(self._h, o.ctypes.data, d.ctypes.data, n, C.byref(opts), out.ctypes.data,
+        self._check(self._lib.vmx_radiance(self._h, o.ctypes.data, d.ctypes.data, n, C.byref(opts), out.ctypes.data,
                                      C.byref(st)))
         return out, st.as_dict()
 
@@ -181,7 +187,7 @@ class Scene:
         rows = local_rows(cam.image_res[1], opts.stripe_rows, opts.rank, opts.world)
         out = np.empty((rows, cam.image_res[0], 5), np.float32)
         st = L.Stats()
-        L.check(L.lib().vmx_render(self._h, C.byref(cam), C.byref(opts), out.ctypes.data, C.byref(st)))
+        self._check(self._lib.vmx_render(self._h, C.byref(cam), C.byref(opts), out.ctypes.data, C.byref(st)))
         return out, st.as_dict()
 
     def render_bruteforce(self, cam, opts, flags=0):
@@ -190,14 +196,14 @@ class Scene:
         rows = local_rows(cam.image_res[1], opts.stripe_rows, opts.rank, opts.world)
         out = np.empty((rows, cam.image_res[0], 5), np.float32)
         st = L.Stats()
-        L.check(L.lib().vmx_render_bruteforce(self._h, C.byref(cam), C.byref(opts), int(flags), out.ctypes.data,
+        self._check(self._lib.vmx_render_bruteforce(self._h, C.byref(cam), C.byref(opts), int(flags), out.ctypes.data,
                                               C.byref(st)))
         return out, st.as_dict()
 
     def render_device(self, cam, opts, d_out_ptr, stream_ptr=None):
         """Same, into device memory (e.g. a torch tensor's data_ptr()) on `stream_ptr`."""
         st = L.Stats()
-        L.check(L.lib().vmx_render_device(self._h, C.byref(cam), C.byref(opts), C.c_void_p(d_out_ptr),
+        self._check(self._lib.vmx_render_device(self._h, C.byref(cam), C.byref(opts), C.c_void_p(d_out_ptr),
                                           C.c_void_p(stream_ptr or 0), C.byref(st)))
         return st.as_dict()
 
