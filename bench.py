@@ -87,7 +87,7 @@ def main():
                     "first device are inside the timed step.  Not combined with torch.distributed.run")
     ap.add_argument("--corrected-spp", type=int, default=64, help="spp of the corrected-sampling (r2 = U) frame")
     ap.add_argument("--reorder", type=lambda v: int(v, 0), default=0,
-                    help="experiment: bounce reordering key (vmx_opts.reserved[5], tools/sort_probe.py); 0 = library default")
+                    help="experiment (A/B library only, VMX_LIB=build/libvermilion_hip_ab.so): bounce reordering key, tools/sort_probe.py")
     args = ap.parse_args()
 
     if args.multi:

@@ -41,7 +41,7 @@ def test_full_size_frame_invariants(sponza):
     # scheduling must not change a single bit
     for kw in (dict(samples_per_batch=3), dict(pipeline=1), dict(pipeline=4), dict(tail_threshold=1),
                dict(max_paths=1 << 20), dict(refill_min=1, shade_min=1), dict(refill_min=64, shade_min=64),
-               dict(refill_min=5, shade_min=40), dict(reorder=0x35, tail_threshold=1), dict(reorder=0x108044, tail_threshold=4096, lds_entries=3),
+               dict(refill_min=5, shade_min=40),
                dict(lds_entries=40), dict(lds_entries=1), dict(collect_counters=True)):
         b, sb = sponza.render(cam, va.make_opts(seed=1, early_stop=False, **kw))
         assert np.array_equal(bits(a), bits(b)), kw
@@ -238,9 +238,11 @@ def test_first_generation_kernels_give_the_same_frames(sponza):
     with va.Scene(pos, nrm, uv, lib=ab) as old:
         for es in (False, True):
             a, sa = sponza.render(cam, va.make_opts(seed=1, early_stop=es))
-            for pl in (2, 3, 0):
-                b, sb = old.render(cam, va.make_opts(seed=1, early_stop=es, pipeline=pl))
-                assert np.array_equal(bits(a), bits(b)), (es, pl)
+            # ... and the bounce-reordering experiment (path_sort.hip) that shares the A/B library
+            for kw in (dict(pipeline=2), dict(pipeline=3), dict(), dict(reorder=0x35, tail_threshold=1),
+                       dict(reorder=0x108044, tail_threshold=4096, lds_entries=3)):
+                b, sb = old.render(cam, va.make_opts(seed=1, early_stop=es, **kw))
+                assert np.array_equal(bits(a), bits(b)), (es, kw)
                 assert sb["samples"] == sa["samples"]
                 if not es:
                     assert sb["rays_secondary"] == sa["rays_secondary"]
@@ -252,3 +254,5 @@ def test_first_generation_kernels_give_the_same_frames(sponza):
             assert np.array_equal(bits(r0), bits(r2))
     with pytest.raises(va.VmxError, match="A/B library"):
         sponza.render(cam, va.make_opts(seed=1, pipeline=2))
+    with pytest.raises(va.VmxError, match="A/B library"):
+        sponza.render(cam, va.make_opts(seed=1, early_stop=False, reorder=0x35, tail_threshold=1))

@@ -1,5 +1,6 @@
 """Bounce reordering (path_sort.hip): per-kernel time of the bench frame for a list of sort keys, and a bit-compare of
-every frame with the unsorted one.   python tools/sort_probe.py [spp] [mode,mode,...]
+every frame with the unsorted one.   VMX_LIB=build/libvermilion_hip_ab.so python tools/sort_probe.py [spp] [mode,mode,...]
+(the experiment lives in the A/B library: make -C vermilion_amd/csrc ab)
 mode = obits | dbits << 4 | dir_major << 8 | chunk_log2 << 12 | shade_sorted << 20   (hex accepted)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -439,6 +439,11 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
         wk.refill_min = tn.refill_min, wk.shade_min = tn.shade_min;
         wk.qids = q[cur];
         IdQueue q_shade = q[cur];
+#ifndef VMX_AB_KERNELS
+        if (tn.sort_mode)
+            return fail(VMX_ERR_INVALID, "bounce reordering (vmx_opts.reserved[5]) is an experiment of the A/B library (make ab): "
+                                         "it never paid for its sort, profiles/r03_bounce_sort.txt");
+#else
         if (!tail && tn.sort_mode) {
             // reorder the live ids by (origin cell, direction cell) of their next rays (path_sort.hip)
             const size_t qsize = (size_t)q[cur].sub_capacity * kSubQueues;
@@ -466,6 +471,7 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
             wk.qids.ids = ws.ids_sorted.p;
             if ((tn.sort_mode >> 20) & 1u) q_shade.ids = ws.ids_sorted.p;
         }
+#endif
         const uint32_t entries = tail ? tn.lds_entries : tn.lds_bounce;
         LaunchCfg cfg = paths_cfg(sc, entries, total, tail ? tail_blocks : trace_blocks);
         rc = bind_stack(sc, tn, entries, cfg.grid, total, wk);
