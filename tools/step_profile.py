@@ -17,7 +17,7 @@ W, H = 1920, 1080
 cam = va.make_camera(c["position"], c["rotation_deg"], W, H, spp, back_size=(3.6, 3.6 * H / W))
 sc = va.Scene(pos, nrm, uv)
 out = torch.empty((H, W, 5), device="cuda")
-o = va.make_opts(seed=1, early_stop=False, reorder=int(os.environ.get("REORDER", "0"), 0))
+o = va.make_opts(seed=1, early_stop=False, reorder=int(os.environ.get("REORDER", "0"), 0), lds_entries=int(os.environ.get("LDSE", "0")))
 sc.render_device(cam, o, out.data_ptr())
 buf = np.zeros((2, 10, 2), dtype=np.uint64)
 ws = lib.vmx_debug_wave_span

@@ -1650,6 +1650,9 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 //     (sp + 1) only where its distance is finite, i.e. where both children were hit (a child hit at +inf
 //     is treated as missed: the reference would pop it again unvisited, `inf > t`);
 //   * the next node is chosen on the scalar unit (s_cselect) and its record fetch issued at once.
+// Round 3: when EVERY lane prunes at a node (both children missed, or beyond the hit so far — a wave's 64 samples of
+// one pixel mostly agree on that too) the pop is done here as well, uniformly (label 5): 12 % of the kernel's
+// wave-steps were whole waves leaving the loop only to pop and come back (tools/step_profile.py).
 // While the lanes agree, none of them prunes and the next node is an inner node, the loop needs no
 // per-lane node reference, no exec masking and no refill test (no lane can finish here).  When lanes
 // disagree or one of them prunes, the node is finished per lane (same values, lane selects) and the
@@ -1716,8 +1719,11 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
         "s_cbranch_vccz 1b\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"                            // nothing may land in s[36:51] after the block
         "s_branch 3f\n"
-        // ---- the lanes part ways here: finish this node per lane (bvh.cpp:103-132)
+        // ---- the lanes part ways here, or some of them prune
         "2:\n\t"
+        "s_cmp_eq_u64 %[pop], exec\n\t"                     // EVERY lane prunes (the common case: both children missed, or
+        "s_cbranch_scc1 5f\n\t"                            // beyond the hit so far): pop here, uniformly, as long as that works
+        // finish this node per lane (bvh.cpp:103-132)
         "v_mov_b32_e32 %[t0], s48\n\t"
         "v_mov_b32_e32 %[t1], s49\n\t"
         "v_cndmask_b32_e32 %[oth], %[t1], %[t0], vcc\n\t"     // stored: go right ? left : right
@@ -1729,6 +1735,44 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
         "v_cndmask_b32_e64 %[cur], %[t2], %[t0], %[pop]\n\t"  // kPop where the lane prunes
         "s_nop 0\n\t"
         "v_addc_co_u32_e32 %[sp], vcc, 0, %[sp], vcc\n\t"
+        "s_branch 4f\n"
+        // ---- uniform pop (bvh.cpp:61-70).  The child taken is pruned in every lane, so the other child — never nearer —
+        // would be popped and pruned at once: it is not pushed at all.  Each lane reads ITS entry below the top; the wave
+        // goes on together while all lanes skip it (near > t), or all take it and it is the same inner node for all of
+        // them (back into the loop) or the same leaf (out, at that leaf).  Anything else — lanes disagree, the bottom
+        // entry (the ray is done) — leaves sp untouched and hands every lane to the general step as "must pop".
+        "5:\n\t"
+        "v_add_u32_e32 %[t0], -1, %[sp]\n\t"
+        "v_lshl_add_u32 %[va], %[t0], 9, %[stk]\n\t"
+        "ds_read_b32 %[t1], %[va]\n\t"                      // node reference of the entry
+        "ds_read_b32 %[t2], %[va] offset:4\n\t"             // its entry distance
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_gt_f32_e32 vcc, %[t2], %[best]\n\t"          // lanes that skip it
+        "s_cbranch_vccz 6f\n\t"
+        "s_cmp_eq_u64 vcc, exec\n\t"
+        "s_cbranch_scc0 7f\n\t"                            // some skip, some take: per lane from here
+        "v_mov_b32_e32 %[sp], %[t0]\n\t"                    // all skip: next entry
+        "s_branch 5b\n"
+        "6:\n\t"
+        "v_readfirstlane_b32 %[soth], %[t1]\n\t"
+        "s_nop 1\n\t"
+        "v_cmp_ne_u32_e32 vcc, %[soth], %[t1]\n\t"
+        "s_cbranch_vccnz 7f\n\t"                           // not the same entry in every lane
+        "s_cmp_ge_u32 %[soth], 0x7ffffffd\n\t"              // leaf (bit 31) or bottom entry: not an inner node
+        "s_cbranch_scc1 8f\n\t"
+        "v_mov_b32_e32 %[sp], %[t0]\n\t"
+        "s_mov_b32 %[scur], %[soth]\n\t"
+        "s_lshl_b32 %[soff], %[scur], 6\n\t"
+        "s_load_dwordx16 s[36:51], %[base], %[soff]\n\t"
+        "s_branch 1b\n"
+        "8:\n\t"
+        "s_bitcmp1_b32 %[soth], 31\n\t"
+        "s_cbranch_scc0 7f\n\t"                            // the bottom entry: the general step finishes the rays
+        "v_mov_b32_e32 %[sp], %[t0]\n\t"
+        "s_mov_b32 %[scur], %[soth]\n\t"
+        "s_branch 3f\n"
+        "7:\n\t"
+        "v_mov_b32_e32 %[cur], 0x7ffffffd\n\t"              // kPop
         "s_branch 4f\n"
         "3:\n\t"
         "v_mov_b32_e32 %[cur], %[scur]\n"
