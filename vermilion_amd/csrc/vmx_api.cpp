@@ -120,7 +120,7 @@ struct Workspace {
     DevBuf<unsigned int> ids[2], id_counts;             // split wavefront: live path ids
     DevBuf<unsigned int> sort_keys[2], ids_sorted;      // bounce reordering (path_sort.hip)
     DevBuf<unsigned char> sort_tmp;
-    DevBuf<unsigned char> cam_inner, cam_tris;          // per-frame camera-relative scene tables
+    DevBuf<unsigned char> cam_inner;                    // per-frame camera-relative scene tables: 8 node copies, then the triangles
     DevBuf<unsigned char> rad;          // float4 per path of a pass
     DevBuf<unsigned char> accum;        // float4 per local pixel
     DevBuf<unsigned int> count, cursor, active[2], next_count;
@@ -132,7 +132,7 @@ struct Workspace {
     void release() {
         queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), heads.release(), overflow_stack.release();
         rayA.release(), state.release(), hit.release(), thr.release();
-        ids[0].release(), ids[1].release(), id_counts.release(), cam_inner.release(), cam_tris.release();
+        ids[0].release(), ids[1].release(), id_counts.release(), cam_inner.release();
         sort_keys[0].release(), sort_keys[1].release(), ids_sorted.release(), sort_tmp.release();
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
@@ -701,10 +701,12 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     if (split_any) {
         // camera-relative copies of the node and triangle records for this frame's origin
         const size_t n_inner = std::max<size_t>(sc->n_inner, 1);
-        if (ws.cam_inner.ensure(n_inner * 64 * 8) || ws.cam_tris.ensure((size_t)sc->ntris * 64))
+        // (one allocation, node copies first: the assembly loop of k_trace_w<0> addresses a triangle record by a
+        // 32-bit offset from the node table's base)
+        if (ws.cam_inner.ensure(n_inner * 64 * 8 + (size_t)sc->ntris * 64))
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the camera tables");
         LAUNCH_TRY(launch_camera_tables(sc->dev, sc->n_inner, fr.px, fr.py, fr.pz, ws.cam_inner.p,
-                                        ws.cam_tris.p, s));
+                                        ws.cam_inner.p + n_inner * 64 * 8, s));
         launches++;
     }
     HIP_TRY(hipMemsetAsync(ws.counters.p, 0, sizeof(DevCounters), s));
@@ -781,7 +783,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;
             wk.band_items = wk.band_slots * S;
             wk.pixel_major = 1;
-            wk.cam_inner = ws.cam_inner.p, wk.cam_tris = ws.cam_tris.p;
+            wk.cam_inner = ws.cam_inner.p, wk.cam_tris = ws.cam_inner.p + std::max<size_t>(sc->n_inner, 1) * 64 * 8;
             wk.cam_n_inner = sc->n_inner;
             LaunchCfg cfg = paths_cfg(sc, tn.lds_primary, (uint64_t)n_pad * S, tb);
             rc = bind_stack(sc, tn, tn.lds_primary, cfg.grid, (uint64_t)n_pad * S, wk);

@@ -33,6 +33,9 @@
 #include "vmx_kernels.h"
 #include <type_traits>
 
+#ifndef VMX_CAM_BATCH
+#define VMX_CAM_BATCH 16  // steps of a camera-ray wave between two refill tests (a descent counts as 5)
+#endif
 #ifndef VMX_TRACE_WAVES_PER_SIMD
 #define VMX_TRACE_WAVES_PER_SIMD 7  // register budget of the trace kernel: 512 / 7 -> 72 VGPRs
 #endif
@@ -1662,11 +1665,12 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
 //   out: cur (per lane: next node, leaf or kPop), sp; returns the number of nodes done (diagnostic build; else 0)
 // The record lives in s[36:51] (an inline-asm operand cannot be a 16-register tuple).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, float ix, float iy, float iz, float best,
-                                                    uint32_t stk_lds, const char *base, uint32_t scur,
-                                                    int lds_entries, unsigned long long trav) {
+__device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, float ix, float iy, float iz, float &best,
+                                                    int &slot, float dx, float dy, float dz, uint32_t stk_lds,
+                                                    const char *base, uint32_t tri_delta, uint32_t scur, int lds_entries,
+                                                    unsigned long long trav) {
     float t0, t1, t2, n0, tf, n1, near, far;
-    uint32_t va, oth, soff, soth, done = 0;
+    uint32_t va, oth, soff, soth, sidx, cnt, done = 0;
     unsigned long long tmp, pop;
     asm volatile(
         "s_mov_b64 exec, %[trav]\n\t"
@@ -1713,7 +1717,7 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
         "s_lshl_b32 %[soff], %[scur], 6\n\t"
         "s_bitcmp1_b32 %[scur], 31\n\t"                       // the child taken is a leaf?
         "v_addc_co_u32_e32 %[sp], vcc, 0, %[sp], vcc\n\t"
-        "s_cbranch_scc1 3f\n\t"
+        "s_cbranch_scc1 9f\n\t"
         "s_load_dwordx16 s[36:51], %[base], %[soff]\n\t"
         "v_cmp_le_i32_e32 vcc, %[lds], %[sp]\n\t"             // a lane whose next push would leave the LDS levels?
         "s_cbranch_vccz 1b\n\t"
@@ -1769,8 +1773,81 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
         "s_bitcmp1_b32 %[soth], 31\n\t"
         "s_cbranch_scc0 7f\n\t"                            // the bottom entry: the general step finishes the rays
         "v_mov_b32_e32 %[sp], %[t0]\n\t"
-        "s_mov_b32 %[scur], %[soth]\n\t"
-        "s_branch 3f\n"
+        "s_mov_b32 %[scur], %[soth]\n"
+        // ---- uniform leaf (triangle.cpp:4-54 on the camera-relative records of k_camera_tables): every traversing lane
+        // tests every triangle of the leaf, the record comes through the scalar cache into s[36:51]
+        //   s36-38 e1   s39-41 e2   s42-44 tvec = o - v0   s45-47 qvec = cross(tvec, e1)   s48 dot(e2, qvec)
+        // same operations in the same order as the general step; then the uniform pop above
+        "9:\n\t"
+        "s_and_b32 %[sidx], %[scur], 0x3ffffff\n\t"         // leaf slot of the first triangle
+        "s_bfe_u32 %[cnt], %[scur], 0x5001a\n\t"            // triangles in the leaf (5 bits at 26)
+        "s_lshl_b32 %[soff], %[sidx], 6\n\t"
+        "s_add_u32 %[soff], %[soff], %[tdelta]\n\t"
+        "s_load_dwordx16 s[36:51], %[base], %[soff]\n"
+        "10:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f32_e32 %[t0], s41, %[dy]\n\t"               // pvec = cross(d, e2)
+        "v_mul_f32_e32 %[t1], s40, %[dz]\n\t"
+        "v_sub_f32_e32 %[n0], %[t0], %[t1]\n\t"
+        "v_mul_f32_e32 %[t0], s39, %[dz]\n\t"
+        "v_mul_f32_e32 %[t1], s41, %[dx]\n\t"
+        "v_sub_f32_e32 %[tf], %[t0], %[t1]\n\t"
+        "v_mul_f32_e32 %[t0], s40, %[dx]\n\t"
+        "v_mul_f32_e32 %[t1], s39, %[dy]\n\t"
+        "v_sub_f32_e32 %[n1], %[t0], %[t1]\n\t"
+        "v_mul_f32_e32 %[t0], s36, %[n0]\n\t"               // det = dot(e1, pvec)
+        "v_mul_f32_e32 %[t1], s37, %[tf]\n\t"
+        "v_add_f32_e32 %[t0], %[t0], %[t1]\n\t"
+        "v_mul_f32_e32 %[t1], s38, %[n1]\n\t"
+        "v_add_f32_e32 %[near], %[t0], %[t1]\n\t"
+        "v_div_scale_f32 %[t0], %[pop], %[near], %[near], 1.0\n\t"   // inv_det = 1 / det, correctly rounded
+        "v_rcp_f32_e32 %[t1], %[t0]\n\t"
+        "v_div_scale_f32 %[t2], vcc, 1.0, %[near], 1.0\n\t"
+        "v_fma_f32 %[far], -%[t0], %[t1], 1.0\n\t"
+        "v_fmac_f32_e32 %[t1], %[far], %[t1]\n\t"
+        "v_mul_f32_e32 %[far], %[t2], %[t1]\n\t"
+        "v_fma_f32 %[oth], -%[t0], %[far], %[t2]\n\t"
+        "v_fmac_f32_e32 %[far], %[oth], %[t1]\n\t"
+        "v_fma_f32 %[t0], -%[t0], %[far], %[t2]\n\t"
+        "v_div_fmas_f32 %[t0], %[t0], %[t1], %[far]\n\t"
+        "v_div_fixup_f32 %[t0], %[t0], %[near], 1.0\n\t"
+        "v_mul_f32_e32 %[t1], s42, %[n0]\n\t"               // u = dot(tvec, pvec) * inv_det
+        "v_mul_f32_e32 %[t2], s43, %[tf]\n\t"
+        "v_add_f32_e32 %[t1], %[t1], %[t2]\n\t"
+        "v_mul_f32_e32 %[t2], s44, %[n1]\n\t"
+        "v_add_f32_e32 %[t1], %[t1], %[t2]\n\t"
+        "v_mul_f32_e32 %[n0], %[t1], %[t0]\n\t"
+        "v_mul_f32_e32 %[t1], s45, %[dx]\n\t"               // v = dot(d, qvec) * inv_det
+        "v_mul_f32_e32 %[t2], s46, %[dy]\n\t"
+        "v_add_f32_e32 %[t1], %[t1], %[t2]\n\t"
+        "v_mul_f32_e32 %[t2], s47, %[dz]\n\t"
+        "v_add_f32_e32 %[t1], %[t1], %[t2]\n\t"
+        "v_mul_f32_e32 %[tf], %[t1], %[t0]\n\t"
+        "v_mul_f32_e32 %[n1], s48, %[t0]\n\t"               // t = dot(e2, qvec) * inv_det
+        "v_add_f32_e32 %[t1], %[n0], %[tf]\n\t"             // u + v
+        "v_and_b32_e32 %[t2], 0x7fffffff, %[near]\n\t"      // |det|
+        // the next triangle's record can be on its way while this one is judged
+        "s_cmp_lg_u32 %[cnt], 1\n\t"
+        "s_cbranch_scc0 11f\n\t"
+        "s_add_u32 %[soff], %[soff], 64\n\t"
+        "s_load_dwordx16 s[36:51], %[base], %[soff]\n"
+        "11:\n\t"
+        "s_mov_b64 %[tmp], exec\n\t"
+        "v_cmpx_nge_f32_e32 vcc, 0x322bcc77, %[t2]\n\t"     // not (|det| <= float(1e-8))           triangle.cpp:25
+        "v_cmpx_ngt_f32_e32 vcc, 0, %[n0]\n\t"              // not (u < 0)                          :34
+        "v_cmpx_nlt_f32_e32 vcc, 1.0, %[n0]\n\t"            // not (u > 1)
+        "v_cmpx_ngt_f32_e32 vcc, 0, %[tf]\n\t"              // not (v < 0)                          :40
+        "v_cmpx_nlt_f32_e32 vcc, 1.0, %[t1]\n\t"            // not (u + v > 1)
+        "v_cmpx_lt_f32_e32 vcc, 0, %[n1]\n\t"               // t > 0                                :44
+        "v_cmpx_lt_f32_e32 vcc, %[n1], %[best]\n\t"         // strictly nearer: the first tested wins ties (bvh.cpp:90)
+        "v_mov_b32_e32 %[best], %[n1]\n\t"
+        "v_mov_b32_e32 %[slot], %[sidx]\n\t"
+        "s_mov_b64 exec, %[tmp]\n\t"
+        "s_add_u32 %[sidx], %[sidx], 1\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 10b\n\t"
+        "s_branch 5b\n"
         "7:\n\t"
         "v_mov_b32_e32 %[cur], 0x7ffffffd\n\t"              // kPop
         "s_branch 4f\n"
@@ -1778,11 +1855,12 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
         "v_mov_b32_e32 %[cur], %[scur]\n"
         "4:\n\t"
         "s_mov_b64 exec, -1"
-        : [sp] "+v"(sp), [cur] "+v"(cur), [scur] "+s"(scur), [done] "+s"(done), [t0] "=&v"(t0), [t1] "=&v"(t1),
-          [t2] "=&v"(t2), [n0] "=&v"(n0), [tf] "=&v"(tf), [n1] "=&v"(n1), [near] "=&v"(near), [far] "=&v"(far),
-          [va] "=&v"(va), [oth] "=&v"(oth), [soff] "=&s"(soff), [soth] "=&s"(soth), [tmp] "=&s"(tmp), [pop] "=&s"(pop)
-        : [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [best] "v"(best), [stk] "v"(stk_lds), [base] "s"(base),
-          [lds] "s"(lds_entries), [trav] "s"(trav), [inf] "v"(__builtin_inff())
+        : [sp] "+v"(sp), [cur] "+v"(cur), [best] "+v"(best), [slot] "+v"(slot), [scur] "+s"(scur), [done] "+s"(done),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [n0] "=&v"(n0), [tf] "=&v"(tf), [n1] "=&v"(n1),
+          [near] "=&v"(near), [far] "=&v"(far), [va] "=&v"(va), [oth] "=&v"(oth), [soff] "=&s"(soff), [soth] "=&s"(soth),
+          [sidx] "=&s"(sidx), [cnt] "=&s"(cnt), [tmp] "=&s"(tmp), [pop] "=&s"(pop)
+        : [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [dx] "v"(dx), [dy] "v"(dy), [dz] "v"(dz), [stk] "v"(stk_lds),
+          [base] "s"(base), [tdelta] "s"(tri_delta), [lds] "s"(lds_entries), [trav] "s"(trav), [inf] "v"(__builtin_inff())
         : "vcc", "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
           "s48", "s49", "s50", "s51");
     return done;
@@ -2116,7 +2194,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             uni_base = (const char *)inner + (size_t)wave_octant * wk.cam_n_inner * 64;
             // (16 steps per batch here: these waves refill only when all 64 lanes are done; measured 8 / 16 / 32)
 #pragma unroll 1
-            for (int act = 0; act < 16; ++act) {
+            for (int act = 0; act < VMX_CAM_BATCH; ++act) {
                 // all 64 lanes at the same inner node: the assembly loop takes the wave down the tree while that
                 // holds (uniform_descent), the general step goes on from where it stopped
                 const unsigned long long trav = __builtin_amdgcn_ballot_w64(cur != kIdle);
@@ -2128,8 +2206,9 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
 #ifdef VMX_STEP_PROFILE
                         const unsigned long long t0_ = __builtin_readcyclecounter();
 #endif
-                        const uint32_t done = uniform_descent(sp, cur, ix, iy, iz, best, (uint32_t)(uintptr_t)stk, uni_base,
-                                                              c0, lds_entries, trav);
+                        const uint32_t done = uniform_descent(sp, cur, ix, iy, iz, best, slot, dx, dy, dz, (uint32_t)(uintptr_t)stk,
+                                                              uni_base, (uint32_t)((const char *)tris - uni_base), c0, lds_entries,
+                                                              trav);
 #ifdef VMX_STEP_PROFILE
                         act += (int)done;
 #else
