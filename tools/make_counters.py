@@ -83,7 +83,7 @@ def main():
         k["derived"] = d
         kernels[name] = k
     out = {
-        "round": 2,
+        "round": 3,
         "tag": tag,
         "workload": workload,
         "command": "rocprofv3 --kernel-trace --pmc <one group per pass> --output-format csv -- python3 bench.py "

@@ -25,10 +25,12 @@ bool HipIntegratorBase::upload(MeshEngine *mEng) {
         mUploadedTextures == mEng->boundTextures.size())
         return true;
     pos.reserve(faces * 9), nrm.reserve(faces * 9), uv.reserve(faces * 6);
+    float lastUv[6] = {0, 0, 0, 0, 0, 0};
     for (aiMesh *mesh : mEng->sceneMeshes) {
-        // createBVH declares v0uv..v2uv per mesh (meshEngine.cpp:663-667) and assigns them only when the
-        // mesh has UVs: a mesh without UVs carries nothing over from the previous mesh (zeros here)
-        float lastUv[6] = {0, 0, 0, 0, 0, 0};
+        // createBVH declares `glm::vec2 v0uv, v1uv, v2uv;` per mesh (meshEngine.cpp:663-667) and assigns them only
+        // when the mesh has UVs.  What a mesh WITHOUT UVs gets is undefined in the reference — it depends on the
+        // GLM the submodule resolves to (kUvOfMeshesWithoutUvs, HipPathTracer.h)
+        if (kUvOfMeshesWithoutUvs == UvRule::Zero) std::memset(lastUv, 0, sizeof(lastUv));
         for (unsigned f = 0; f < mesh->mNumFaces; ++f) {
             for (int c = 0; c < 3; ++c) {
                 const unsigned i = mesh->mFaces[f].mIndices[c];

@@ -11,6 +11,9 @@
 //     rEng->assignIntegrator(integrator);                 // main.cpp:63
 // or, for every GPU of the node from the one process main.cpp is:
 //     auto integrator = new Vermilion::HipPathTracer(/*seed=*/1, std::vector<int>{0, 1, 2, 3, 4, 5, 6, 7});
+// (the device-list form — vmx_multi_*, peer copies between DIFFERENT devices — has been rehearsed with every entry
+// on one GPU only: no box with two GPUs was available to this repository's test runs.  tests/test_gpu_multi.py::
+// test_two_physical_devices_equal_one and `bench.py --multi 0,1,...` exercise it the first time one is.)
 #pragma once
 #include <utility>
 #include <vector>
@@ -19,6 +22,15 @@
 #include "vermilion_hip.h"
 
 namespace Vermilion {
+
+// UVs of a mesh WITHOUT texture coordinates.  MeshEngine::createBVH (meshEngine.cpp:663-667) declares
+// `glm::vec2 v0uv, v1uv, v2uv;` inside its per-mesh loop and assigns them only under HasTextureCoords(0), so for such a
+// mesh the reference passes default-constructed vec2s to Triangle — and what those hold is the GLM version's choice:
+// zeros with GLM <= 0.9.8 (or GLM_FORCE_CTOR_INIT), indeterminate with GLM 0.9.9's default (in practice the stack
+// slots still hold the previous mesh's last face).  extern/glm is an unpinned submodule (.gitmodules:7-9): neither
+// reading can be pinned.  It matters only for mixed UV / no-UV scenes with a bound texture.  One switch:
+enum class UvRule { Zero, CarryOverFromPreviousMesh };
+constexpr UvRule kUvOfMeshesWithoutUvs = UvRule::Zero;
 
 // what both adapters share: the device copy of MeshEngine's triangles / textures, the camera marshalling
 // and the pixel write-back through Camera::setPixelValue
