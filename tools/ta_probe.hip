@@ -149,6 +149,78 @@ __global__ void __launch_bounds__(256, 6) k_quad(const float4 *__restrict__ tab,
     out[gid] = acc + (float)idx;
 }
 
+// quad-cooperative fetch with the 4x4 transposition through LDS instead of registers (round 3 experiment): every lane
+// writes its four 16-byte pieces into the 64-byte slots of their owners (4 KB of staging per wave) and reads its own
+// record back: 4 ds_write_b128 + 4 ds_read_b128 instead of 32 v_cndmask_b32_dpp + 8 s_mov + 4 s_nop.
+// SWZ: XOR the 16-byte piece position with bits of the owner's index so that the 16 quads do not all hit the same banks
+template <int SWZ>
+__global__ void __launch_bounds__(256, 6) k_quad_lds(const float4 *__restrict__ tab, float *out) {
+    __shared__ float4 stage[4][64 * 4];  // per wave: 64 records x 4 pieces
+    const uint32_t lane = threadIdx.x & 63u, ql = lane & 3u, wave = threadIdx.x >> 6;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool wants = ((gid * 2246822519u) >> 8) % 100u < c_percent;
+    uint32_t idx = (gid * 7919u) & c_mask;
+    float acc = (float)gid * 1e-6f;
+    float4 *st = stage[wave];
+    auto slot = [&](uint32_t owner, uint32_t piece) {
+        const uint32_t p = SWZ == 0 ? piece : SWZ == 1 ? (piece ^ (owner & 3u)) : (piece ^ ((owner >> 2) & 3u));
+        return owner * 4u + p;
+    };
+    uint32_t w[4], r[4];
+    for (uint32_t i = 0; i < 4; ++i) w[i] = slot((lane & ~3u) + i, ql), r[i] = slot(lane, i);
+#pragma unroll 1
+    for (int s = 0; s < kSteps; ++s) {
+        const uint32_t mine = wants ? idx : 0u;  // a lane without a record of its own fetches record 0 (hot), as the kernel does
+        float4 x[4];
+#define FETCH(i)                                                                                        \
+    {                                                                                                   \
+        const uint32_t rr = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, (i) * 0x55, 0xF, 0xF, true);  \
+        x[i] = tab[rr * 4 + ql];                                                                        \
+    }
+        FETCH(0) FETCH(1) FETCH(2) FETCH(3)
+#undef FETCH
+        st[w[0]] = x[0], st[w[1]] = x[1], st[w[2]] = x[2], st[w[3]] = x[3];
+        __builtin_amdgcn_wave_barrier();
+        const float4 b0 = st[r[0]], b1 = st[r[1]], b2 = st[r[2]], b3 = st[r[3]];
+        __builtin_amdgcn_wave_barrier();
+        if (wants) {
+            acc = consume(b0, b1, b2, make_float2(b3.x, b3.y), acc);
+            idx = next_index(idx, acc);
+        }
+    }
+    out[gid] = acc + (float)idx;
+}
+// the register form with unconditional loads (as the kernel does), for a like-for-like comparison
+__global__ void __launch_bounds__(256, 6) k_quad_uncond(const float4 *__restrict__ tab, float *out) {
+    const uint32_t lane = threadIdx.x & 63u, ql = lane & 3u;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool wants = ((gid * 2246822519u) >> 8) % 100u < c_percent;
+    uint32_t idx = (gid * 7919u) & c_mask;
+    float acc = (float)gid * 1e-6f;
+#pragma unroll 1
+    for (int s = 0; s < kSteps; ++s) {
+        const uint32_t mine = wants ? idx : 0u;
+        float4 x[4];
+#define FETCH(i)                                                                                        \
+    {                                                                                                   \
+        const uint32_t rr = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, (i) * 0x55, 0xF, 0xF, true);  \
+        x[i] = tab[rr * 4 + ql];                                                                        \
+    }
+        FETCH(0) FETCH(1) FETCH(2) FETCH(3)
+#undef FETCH
+        float4 a0, a1, a2, a3, b0, b1, b2, b3;
+        xchg_pair_1(x[0], x[1], a0, a1, 0x5555555555555555ull, 0xAAAAAAAAAAAAAAAAull);
+        xchg_pair_1(x[2], x[3], a2, a3, 0x5555555555555555ull, 0xAAAAAAAAAAAAAAAAull);
+        xchg_pair_2(a0, a2, b0, b2, 0x3333333333333333ull, 0xCCCCCCCCCCCCCCCCull);
+        xchg_pair_2(a1, a3, b1, b3, 0x3333333333333333ull, 0xCCCCCCCCCCCCCCCCull);
+        if (wants) {
+            acc = consume(b0, b1, b2, make_float2(b3.x, b3.y), acc);
+            idx = next_index(idx, acc);
+        }
+    }
+    out[gid] = acc + (float)idx;
+}
+
 template <class K>
 double run(K kernel, const float4 *tab, float *out, int grid, const char *name, double lanes_frac) {
     hipEvent_t a, b;
@@ -190,6 +262,10 @@ int main() {
             printf("---- table %u KB, %u %% of the lanes\n", recs / 16, pct);
             run(k_lane<8>, tab, out, grid, "per-lane fetch (4 x 16 B per lane)", pct / 100.0);
             run(k_quad<9>, tab, out, grid, "quad fetch + asm cndmask_dpp transpose", pct / 100.0);
+            run(k_quad_uncond, tab, out, grid, "  same, unconditional loads (as k_trace_w<1>)", pct / 100.0);
+            run(k_quad_lds<0>, tab, out, grid, "quad fetch + LDS transposition, plain layout", pct / 100.0);
+            run(k_quad_lds<1>, tab, out, grid, "quad fetch + LDS transposition, piece ^ owner", pct / 100.0);
+            run(k_quad_lds<2>, tab, out, grid, "quad fetch + LDS transposition, piece ^ quad", pct / 100.0);
         }
     }
     {
@@ -202,13 +278,17 @@ int main() {
         std::vector<float> r0((size_t)grid * 256), r1(r0.size());
         hipLaunchKernelGGL(k_lane<0>, dim3(grid), dim3(256), 0, 0, tab, out);
         CK(hipMemcpy(r0.data(), out, r0.size() * 4, hipMemcpyDeviceToHost));
-        for (int v = 0; v < 2; ++v) {
+        for (int v = 0; v < 6; ++v) {
             if (v == 0) hipLaunchKernelGGL(k_quad<3>, dim3(grid), dim3(256), 0, 0, tab, out);
-            else hipLaunchKernelGGL(k_quad<6>, dim3(grid), dim3(256), 0, 0, tab, out);
+            else if (v == 1) hipLaunchKernelGGL(k_quad<6>, dim3(grid), dim3(256), 0, 0, tab, out);
+            else if (v == 2) hipLaunchKernelGGL(k_quad_uncond, dim3(grid), dim3(256), 0, 0, tab, out);
+            else if (v == 3) hipLaunchKernelGGL(k_quad_lds<0>, dim3(grid), dim3(256), 0, 0, tab, out);
+            else if (v == 4) hipLaunchKernelGGL(k_quad_lds<1>, dim3(grid), dim3(256), 0, 0, tab, out);
+            else hipLaunchKernelGGL(k_quad_lds<2>, dim3(grid), dim3(256), 0, 0, tab, out);
             CK(hipMemcpy(r1.data(), out, r1.size() * 4, hipMemcpyDeviceToHost));
             size_t bad = 0;
             for (size_t i = 0; i < r0.size(); ++i) bad += r0[i] != r1[i];
-            printf("check %s vs v0: %zu mismatches\n", v == 0 ? "v3" : "v6", bad);
+            printf("check variant %d vs v0: %zu mismatches\n", v, bad);
         }
     }
     return 0;

@@ -667,8 +667,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the path arrays although " + std::to_string(mem_budget >> 20) +
                                            " MB were reported free: set VMX_MEM_BUDGET_MB or vmx_opts.reserved[1] (paths per pass)");
         if (rc) return rc;
-        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_primary + 1) * 512, count, &tb));
-        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, &tbb));
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_primary + 1) * 512, count, false, &tb));
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, true, &tbb));
         if (tb < 1 || tbb < 1) return fail(VMX_ERR_HIP, "trace kernel does not fit on a CU");
     }
 #ifdef VMX_AB_KERNELS
@@ -1239,7 +1239,7 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     {
         rc = ensure_paths(sc, n, pa, qi);
         if (rc) return rc;
-        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, &tb));
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, true, &tb));
         HIP_TRY((hipError_t)query_paths_blocks_per_cu(kPathsBlock, lds_paths, count, &rb));
     }
     DevBuf<float> d_o, d_d;

@@ -112,7 +112,7 @@ int launch_camera_tables(const SceneDev &sc, uint32_t n_inner, float ox, float o
 int launch_raygen(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
 int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                    DevCounters *counters, bool count, bool from_queue, LaunchCfg cfg, void *stream);
-int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks);
+int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, bool from_queue, int *blocks);
 // ... and the wide shading kernel: RayCast tail + Radiance step + id compaction
 int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                  IdQueue qout, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream);

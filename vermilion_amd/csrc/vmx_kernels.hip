@@ -1928,6 +1928,9 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             const bool leaf = (int)cur < 0;
             float4 q0, q1, q2, q3;
             // byte offset of this lane's record (0 while the lane is not traversing)
+            // (round 3: the same transposition through LDS — 4 ds_write_b128 + 4 ds_read_b128 instead of the 32 DPP
+            // selects — was measured in the kernel as well: its 4 KB of staging per wave cost waves or LDS stack levels,
+            // 50.5 ms for the bounce stage against 42.9; profiles/r03_lds_transpose.txt, tools/ta_probe.hip)
             quad_fetch_record((const char *)inner,
                               cur == kIdle ? 0u : (leaf ? sc.tri_off + (cur & kLeafStartMask) * 48u : (cur << 6)),
                               lane, q0, q1, q2, q3);
@@ -2845,17 +2848,17 @@ int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pi
     return launch_status();
 }
 
-int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *blocks) {
-    int a = 0, b = 0;
+int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, bool from_queue, int *blocks) {
+    int a = 0;
     hipError_t e;
     if (count) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 0>, (int)block, lds_bytes);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_q<true, 1>, (int)block, lds_bytes);
+        e = from_queue ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 1>, (int)block, lds_bytes)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 0>, (int)block, lds_bytes);
     } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_w<0>, (int)block, lds_bytes);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_w<1>, (int)block, lds_bytes);
+        e = from_queue ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_w<1>, (int)block, lds_bytes)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_w<0>, (int)block, lds_bytes);
     }
-    if (blocks) *blocks = a < b ? a : b;
+    if (blocks) *blocks = a;
     return (int)e;
 }
 
