@@ -321,6 +321,14 @@ def test_tiny_scenes_and_leaf_sizes(ntris, leaf):
     img, _ = p.gpu.render(cam, va.make_opts(seed=2))
     ref, _ = p.cpu.render(cam, va.make_opts(seed=2))
     assert np.array_equal(bits(img), bits(ref))
+    # the split pipeline at 64 samples per pixel: a camera-ray wave is one pixel, so k_trace_w<0>'s assembly loop takes
+    # whole waves through leaves of 1 ... 31 triangles and through the uniform pops (round 3)
+    cam64 = va.make_camera(c0["position"], c0["rotation_deg"], 40, 24, 64)
+    ref64, rst = p.cpu.render(cam64, va.make_opts(seed=2, early_stop=False))
+    for kw in ({"pipeline": 4}, {"pipeline": 4, "lds_entries": 2}):
+        img64, st = p.gpu.render(cam64, va.make_opts(seed=2, early_stop=False, **kw))
+        assert np.array_equal(bits(img64), bits(ref64)), kw
+        assert st["rays_secondary"] == rst["rays_secondary"]
     p.close()
 
 
