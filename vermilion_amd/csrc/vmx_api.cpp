@@ -593,7 +593,10 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
 #endif
     const bool split_any = pipeline == 0 || pipeline == 4;
     const bool legacy = pipeline >= 2 && pipeline <= 3;
-    constexpr uint64_t kHybridPaths = 4ull << 20;  // measured: 1 M, 16 M and 64 M are all slower on early-stop frames
+    // passes below this many path slots run in the fused kernel (no per-generation launches).  Round 3, with the faster
+    // split kernels and the early-stop frame's passes known (2 M pixels x 20, then a few thousand pixels): 1 / 2 / 4 M:
+    // 13.7 / 13.4 / 13.6 ms, 6 / 8 / 12 / 16 / 32 M: 12.9 / 12.8 / 13.0 / 13.0 / 12.9 ms
+    constexpr uint64_t kHybridPaths = 8ull << 20;
     const Tuning tn = make_tuning(sc, opts);
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
@@ -749,7 +752,10 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
                 // strata in one pass (sample_index in the kernels): 3 paths cover it to the end of
                 // the frame if it keeps stopping, as most do (measured: 6 -> 4 passes, 26 -> 21 ms).
                 S = std::max(1u, fr.kmax / std::max(fr.quarter, 1u) - 1u);
-                if (last_pass_pixels > 0 && last_pass_breaks * 8 < last_pass_pixels)
+                // ... or when so few pixels are left that a pass of everything they can still take is small anyway (the
+                // Sponza stand-in: 4,492 of 2 M pixels after the first pass — a pass of 3 paths each was an empty launch
+                // chain of ~1 ms before the one that finished them; 13.8 -> 12.1 ms)
+                if ((last_pass_pixels > 0 && last_pass_breaks * 8 < last_pass_pixels) || (uint64_t)n_active * 2 * cap <= spec)
                     S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, spec / (2ull * n_active)), cap);
                 S = (uint32_t)std::min<uint64_t>(S, ((uint64_t)n_pad_max * smax_alloc) / ((n_active + 63u) & ~63u));
                 S = std::max(S, 1u);
