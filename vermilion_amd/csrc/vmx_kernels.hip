@@ -2260,8 +2260,12 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
 //          from (pixel, sample) instead of being stored by the trace kernel
 //   SRC 1: queued path ids; ray, RNG and accumulated colour come from the arrays
 // ---------------------------------------------------------------------------
+#ifndef VMX_SHADE_WPS
+#define VMX_SHADE_WPS 7  // waves per SIMD k_shade is compiled for (<= 72 VGPRs): left to itself hipcc takes 100 (5 waves) since the
+                        // cosf/sinf path came in; k_shade<0> 14.6 ms at 5-6 waves (the cap at 6 spills into the hot path), 13.1 at 7, 13.4 at 8
+#endif
 template <int SRC, bool TEX>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, VMX_SHADE_WPS)
 k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, IdQueue qout, uint32_t max_chunks,
         DevCounters *ctr) {
     const float2 *__restrict__ hits = (const float2 *)pa.hit;
