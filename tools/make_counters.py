@@ -27,7 +27,9 @@ N_SIMD, N_CU, NOMINAL_HZ = 1024, 256, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 
 
 def longest(pass_dir, pat):
     out = {}
-    for f in glob.glob(os.path.join(pass_dir, "*", "*counter_collection.csv")):
+    # (gpurun merges a call's output into the local directory: keep only the newest run of a pass)
+    files = sorted(glob.glob(os.path.join(pass_dir, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:
         kt = f.replace("counter_collection", "kernel_trace")
         dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
                for r in csv.DictReader(open(kt)) if pat in r["Kernel_Name"]}
@@ -95,7 +97,7 @@ def main():
         "kernels": kernels,
     }
     json.dump(out, open(os.path.join(ROOT, "profiles", "counters.json"), "w"), indent=1)
-    for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"trace_{tag}", "*", "*kernel_stats.csv")):
+    for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"trace_{tag}", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1:]:
         shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
     for name, k in kernels.items():
         d = k["derived"]
