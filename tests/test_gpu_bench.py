@@ -1,0 +1,68 @@
+"""bench.py's contract with the driver (one JSON line on rank 0, the fields BASELINE.json's metric needs, the
+`roofline` and `cpu_baseline` objects) — on a small frame (large enough for the split pipeline: >= 8 M path slots), in
+its three launch forms."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--width", "640", "--height", "360", "--spp", "64", "--steps", "2", "--warmup", "1", "--cpu-spp", "4",
+         "--corrected-spp", "8"]
+
+
+def run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def check_common(d, n_gpus):
+    assert d["metric"].startswith("Mrays/sec") and d["unit"] == "Mrays/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == n_gpus and d["steps"] == 2 and d["warmup"] == 1
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["rays_per_frame"] / d["ms_per_step"] / 1e3) / d["value"] < 0.02
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r
+
+
+def test_single_gpu_line_carries_roofline_cpu_baseline_and_the_extra_frames():
+    d = run([sys.executable, "bench.py"] + SMALL)
+    check_common(d, 1)
+    assert d["scaling"] in ("weak", "strong")
+    # (the PMC counters in profiles/ belong to the 1920x1080x256 frame: on another workload the fractions are null,
+    # the work-based figure is computed from the live counters pass and is always there)
+    r = d["roofline"]
+    assert r["frac"] is None and "note" in r
+    tc = r["other_kernels"]["trace_camera"] if "trace_camera" in r.get("other_kernels", {}) else r
+    assert 0 < tc["useful_valu_frac"] <= 1 and tc["work"]["rays"] == 640 * 360 * 64
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mrays/s" and cb["sample"]
+    rf = d["reference_frame"]
+    assert rf["ms_per_frame"] > 0 and rf["passes"] >= 1 and sum(rf["kernel_ms"].values()) <= rf["device_ms"] * 1.02
+    cf = d["corrected_frame"]
+    assert cf["spp"] == 8 and cf["rays_per_sample"] > 5 and cf["Mrays_per_s"] > 0
+    assert d["bruteforce_frame"]["ms_per_frame"] > 0 and d["quality_bvh"]["inner_visits_per_ray"] > 0
+
+
+def test_multi_device_form_in_one_process():
+    d = run([sys.executable, "bench.py", "--multi", "0,0"] + SMALL)
+    check_common(d, 2)
+    assert d["config"]["distinct_devices"] == 1 and "vmx_multi" in d["config"]["parallelism"]
+    assert d["reference_frame"]["ms_per_frame"] > 0
+
+
+def test_two_ranks_under_torch_distributed_run():
+    """the driver's N > 1 launch line, rehearsed on the one GPU (both ranks on device 0, frames gathered with gloo)"""
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", "29533", "bench.py", "--gpus", "2", "--backend", "gloo", "--device", "0", "--no-extras"] + SMALL)
+    check_common(d, 2)
+    assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("stripes")
