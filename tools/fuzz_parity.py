@@ -1,0 +1,47 @@
+"""Differential fuzz of the production kernels against the CPU oracle (run on the GPU box; not part of the test suite):
+random triangle soups (the generators of tests/test_gpu_parity.py), random cameras inside and outside the geometry,
+64 ... 256 samples per pixel (camera-ray waves of one pixel: the assembly loop with its uniform pops and leaves), leaf
+sizes 1 ... 16, all four tree builders (device-built trees: the oracle traverses the exported tree), both samplings, several
+LDS stack depths.  Frames, sample counts and ray counts must be bit-identical.   python tools/fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import oracle_lib as O
+import vermilion_amd as va
+from test_gpu_parity import _random_soup, bits
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    kind = ["sheets", "duplicates", "slivers", "scales"][rng.integers(0, 4)]
+    n = int(rng.choice([3, 40, 300, 2500, 12000]))
+    leaf = int(rng.choice([1, 2, 4, 7, 16]))
+    builder = int(rng.choice([0, 0, 1, 2, 3]))
+    spp = int(rng.choice([64, 128, 256]))
+    sampling = int(rng.choice([0, 0, 1, 0x100]))
+    es = bool(rng.integers(0, 2))
+    W, H = (48, 32) if spp >= 128 else (64, 40)
+    pos, nrm, uv = _random_soup(rng, n, kind)
+    cpos = rng.uniform(-900, 900, 3) if rng.random() < 0.5 else rng.uniform(-1900, 1900, 3) * np.array([1, 0.25, 1]) + np.array([0, 500, 0])
+    rot = rng.uniform(-180, 180, 3) * np.array([0.3, 1.0, 0.1])
+    cam = va.make_camera(tuple(float(v) for v in cpos), tuple(float(v) for v in rot), W, H, spp, back_size=(3.6, 3.6 * H / W))
+    kw = [{"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1}, {"pipeline": 4, "lds_entries": int(rng.choice([1, 3, 6, 40]))}, {}][rng.integers(0, 4)]
+    try:
+        with va.Scene(pos, nrm, uv, leaf_size=leaf, builder=builder) as g:
+            osc = O.OracleScene(pos, nrm, uv, leaf_size=leaf, tree=g.bvh() if builder else None)
+            opts = va.make_opts(seed=int(rng.integers(1, 1 << 30)), early_stop=es, sampling=sampling, **kw)
+            img, st = g.render(cam, opts)
+            ref, rst = osc.render(cam, opts)
+            same = np.array_equal(bits(img), bits(ref)) and st["samples"] == rst["samples"]
+            osc.close()
+    except va.VmxError as e:  # e.g. LBVH deeper than the reference's 64-entry stack on many coincident centroids
+        print(f"case {case}: {kind} n={n} leaf={leaf} builder={builder}: {e}")
+        continue
+    bad += not same
+    print(f"case {case:3d}: {kind:10s} n={n:5d} leaf={leaf:2d} builder={builder} spp={spp:3d} sampling={sampling:#x} es={int(es)} {kw} -> "
+          f"{'ok' if same else 'MISMATCH'} ({st['rays_primary'] + st['rays_secondary']} rays)", flush=True)
+print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
