@@ -593,10 +593,11 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
 #endif
     const bool split_any = pipeline == 0 || pipeline == 4;
     const bool legacy = pipeline >= 2 && pipeline <= 3;
-    // passes below this many path slots run in the fused kernel (no per-generation launches).  Round 3, with the faster
-    // split kernels and the early-stop frame's passes known (2 M pixels x 20, then a few thousand pixels): 1 / 2 / 4 M:
-    // 13.7 / 13.4 / 13.6 ms, 6 / 8 / 12 / 16 / 32 M: 12.9 / 12.8 / 13.0 / 13.0 / 12.9 ms
-    constexpr uint64_t kHybridPaths = 8ull << 20;
+    // passes below this many path slots run in the fused kernel (no per-generation launches): 4 M (1, 16 and 64 M were
+    // all slower on early-stop frames in round 1; a full 7.4 M-path pass takes 5.1 ms fused, 3.6 ms split).  The passes
+    // that FOLLOW the first one of an early-stop frame are different: many slots, few of them valid (pixels that stopped
+    // a stratum take 3 of up to 1024) — they run fused up to 32 M slots (round 3: 13.6 -> 12.9 ms before the pass merge)
+    constexpr uint64_t kHybridPaths = 4ull << 20, kHybridLeftover = 32ull << 20;
     const Tuning tn = make_tuning(sc, opts);
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
@@ -768,7 +769,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         const uint32_t n_pad = (n_active + 63u) & ~63u;
         const uint32_t tiles8 = (((n_pad + sc->block - 1) / sc->block) + 7u) & ~7u;
         // the form this pass runs in
-        const bool split = pipeline == 4 || (pipeline == 0 && (uint64_t)n_pad * S >= kHybridPaths);
+        const bool split = pipeline == 4 || (pipeline == 0 && (uint64_t)n_pad * S >= ((fr.early_stop && passes > 0) ? kHybridLeftover : kHybridPaths));
         const bool refill = pipeline == 1 || (pipeline == 0 && !split);
         const bool mega = refill || pipeline == 3;
         (void)mega;
