@@ -122,6 +122,7 @@ struct Workspace {
     DevBuf<unsigned char> sort_tmp;
     DevBuf<unsigned char> cam_inner;                    // per-frame camera-relative scene tables: 8 node copies, then the triangles
     DevBuf<unsigned char> rad;          // float4 per path of a pass
+    DevBuf<unsigned long long> rad_mask;  // split pipeline: one bit per path, "its radiance was stored" (PathArrays::rad_mask)
     DevBuf<unsigned char> accum;        // float4 per local pixel
     DevBuf<unsigned int> count, cursor, active[2], next_count;
     DevBuf<DevCounters> counters;
@@ -130,7 +131,7 @@ struct Workspace {
     uint32_t order_w = 0, order_rows = 0;
     EventPool events;
     void release() {
-        queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), heads.release(), overflow_stack.release();
+        queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), rad_mask.release(), heads.release(), overflow_stack.release();
         rayA.release(), state.release(), hit.release(), thr.release();
         ids[0].release(), ids[1].release(), id_counts.release(), cam_inner.release();
         sort_keys[0].release(), sort_keys[1].release(), ids_sorted.release(), sort_tmp.release();
@@ -404,6 +405,7 @@ int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[2]) {
     pa.rayA = ws.rayA.p, pa.state = ws.state.p;
     pa.hit = ws.hit.p, pa.rad = ws.rad.p;
     pa.thr = nullptr;
+    pa.rad_mask = nullptr;  // render_impl switches it on for its split passes
     if (sc->dev.tex) {
         if (ws.thr.ensure(nslots * 16)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the throughput plane");
         pa.thr = ws.thr.p;
@@ -684,6 +686,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     (void)sub_cap, (void)pb, (void)bb;
 #endif
     if (ws.heads.ensure(kSubQueues * 32)) return fail(VMX_ERR_NOMEM, "work heads");
+    if (ws.rad_mask.ensure(((size_t)n_pad_max * smax + 63) / 64 + 8)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the radiance mask");
+    if (split_any) pa.rad_mask = ws.rad_mask.p;
     if (ws.rad.ensure((size_t)n_pad_max * smax * 16) || ws.accum.ensure((size_t)npix * 16) ||
         ws.count.ensure(npix) || ws.cursor.ensure(npix) || ws.active[0].ensure(npix) ||
         ws.active[1].ensure(npix) || ws.next_count.ensure(32) || ws.counters.ensure(1))
@@ -863,7 +867,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         TimedLaunch tr{ws.events.get(), ws.events.get(), -1, VMX_K_RESOLVE};
         if (!tr.a || !tr.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(tr.a, s));
-        LAUNCH_TRY(launch_resolve(fr, ws.active[cur_list].p, n_active, S, split || refill, ws.rad.p, px, ws.active[cur_list ^ 1].p,
+        LAUNCH_TRY(launch_resolve(fr, ws.active[cur_list].p, n_active, S, split || refill, ws.rad.p, split ? pa.rad_mask : nullptr, px, ws.active[cur_list ^ 1].p,
                                   ws.next_count.p, d_out, ws.counters.p, s));
         HIP_TRY(hipEventRecord(tr.b, s));
         timed.push_back(tr);

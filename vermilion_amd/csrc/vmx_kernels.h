@@ -32,6 +32,11 @@ struct PathArrays {
     void *hit;    // float2 (t of the BVH query, bits(leaf slot or -1))
     void *rad;    // float4 accumColour, updated in place; final when the path ends
     void *thr;    // float4 accumRadiance (rgb); only with a bound texture (else it stays 1,1,1)
+    // one bit per path id: rad[pid] holds something k_resolve has to read — the path went on past its first hit, or
+    // its first hit already gave it a non-zero colour.  ~85 % of the bench frame's paths end black at their first hit:
+    // k_shade<0> does not store their radiance and k_resolve adds an exact +0 instead of loading it.  NULL: every
+    // path's radiance is in `rad` (fused kernel, vmx_radiance)
+    unsigned long long *rad_mask;
 };
 
 // compacted list of live path ids: kSubQueues sub-lists, each `sub_capacity` ids long
@@ -122,7 +127,7 @@ int launch_tail(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathA
 int launch_radiance_init_ids(const float *o, const float *d, uint32_t n, uint64_t seed, PathArrays pa,
                              IdQueue qout, void *stream);
 int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,
-                   bool pixel_major, const void *rad, PixelStateDev px, unsigned int *next_active,
+                   bool pixel_major, const void *rad, const unsigned long long *rad_mask, PixelStateDev px, unsigned int *next_active,
                    unsigned int *next_count, float *out_rgbaz, DevCounters *counters, void *stream);
 // BruteForceTracer::Render (integrators.cpp:9-186): one lane per pixel of `order` (tile-ordered local pixels)
 int launch_bruteforce(const SceneDev &sc, const FrameDev &fr, const unsigned int *order, uint32_t npix, uint32_t flags,

@@ -2325,7 +2325,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             cast_finish<true, SRC == 0>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom,
                                         s_cam_op);
             st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
-            rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
+            if (SRC != 0 || !pa.rad_mask) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
         }
         bool alive = st == kPathNextRay;
         // (gathering the block's ~10 % of angles in LDS to evaluate cos/sin in full waves was measured:
@@ -2339,6 +2339,15 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             ray_store(pa, pid, P);
             rng_store(pa, pid, P.rng);
             if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, 1.f);
+        }
+        if (SRC == 0 && pa.rad_mask) {
+            // camera paths: most end at their first hit with accumColour.rgb == 0 (no light sphere hit): nothing to store
+            // for them, k_resolve adds +0 (x + 0 == x bit for bit; the sums are never -0).  A wave's 64 paths are one
+            // aligned word of the mask (path ids of an item are consecutive, 256 per block)
+            const bool need = run && (alive || P.ar != 0.f || P.ag != 0.f || P.ab != 0.f);
+            if (need) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
+            const unsigned long long word = __builtin_amdgcn_ballot_w64(need);
+            if ((threadIdx.x & 63u) == 0) pa.rad_mask[(item * blockDim.x + threadIdx.x) >> 6] = word;
         }
         tally_add(tl, fl, run, depth0);
         id_append(qout, item % kSubQueues, alive, pid);
@@ -2373,7 +2382,7 @@ __global__ void k_radiance_init_ids(const float *__restrict__ o, const float *__
 // per-pixel accumulation in sample order + early stop + pixel write (pathtracer.cpp:282-324)
 __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, uint32_t n_active,
                           uint32_t n_pad, uint32_t samples, uint32_t pixel_major, const float4 *__restrict__ rad,
-                          PixelStateDev px,
+                          const unsigned long long *__restrict__ rad_mask, PixelStateDev px,
                           unsigned int *__restrict__ next_active, unsigned int *next_count,
                           float *__restrict__ out, DevCounters *ctr) {
     __shared__ unsigned int s_keep, s_base, s_taken, s_disc, s_done, s_brk;
@@ -2400,12 +2409,26 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
         bool stop = false;
         for (uint32_t j0 = 0; j0 < samples && !stop; j0 += kChunk) {
             float4 buf[kChunk];
+            // rad_mask (split pipeline, pixel-major ids): one bit per path says whether its radiance was stored at all;
+            // the others ended black at their first hit and count as an exact zero
+            unsigned long long w0 = ~0ull, w1 = ~0ull;
+            const size_t pid0 = (size_t)slot * samples + j0;
+            if (rad_mask) {
+                w0 = rad_mask[pid0 >> 6];
+                w1 = rad_mask[min(pid0 + kChunk - 1, total - 1) >> 6];
+            }
 #pragma unroll
             for (uint32_t i = 0; i < kChunk; ++i) {
                 const uint32_t j = j0 + i;
                 size_t idx = pixel_major ? (size_t)slot * samples + j : (size_t)j * n_pad + slot;
-                if (j >= samples || idx >= total) idx = (size_t)slot;  // any valid address; value unused
-                buf[i] = rad[idx];
+                bool stored = true;
+                if (j >= samples || idx >= total) idx = (size_t)slot, stored = false;  // any valid address; value unused
+                if (rad_mask) {
+                    const size_t pid = pid0 + i;
+                    stored = stored && ((((pid >> 6) == (pid0 >> 6) ? w0 : w1) >> (pid & 63)) & 1ull) != 0;
+                }
+                buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (stored) buf[i] = rad[idx];
             }
 #pragma unroll
             for (uint32_t i = 0; i < kChunk; ++i) {
@@ -2909,11 +2932,11 @@ int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, in
 }
 
 int launch_resolve(const FrameDev &fr, const unsigned int *active, uint32_t n_active, uint32_t samples,
-                   bool pixel_major, const void *rad, PixelStateDev px, unsigned int *next_active,
+                   bool pixel_major, const void *rad, const unsigned long long *rad_mask, PixelStateDev px, unsigned int *next_active,
                    unsigned int *next_count, float *out_rgbaz, DevCounters *counters, void *stream) {
     const uint32_t n_pad = (n_active + 63u) & ~63u;
     hipLaunchKernelGGL(k_resolve, dim3((n_active + 255) / 256), dim3(256), 0, (hipStream_t)stream, fr, active,
-                       n_active, n_pad, samples, pixel_major ? 1u : 0u, (const float4 *)rad, px, next_active,
+                       n_active, n_pad, samples, pixel_major ? 1u : 0u, (const float4 *)rad, pixel_major ? rad_mask : nullptr, px, next_active,
                        next_count, out_rgbaz, counters);
     return launch_status();
 }
