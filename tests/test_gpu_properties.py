@@ -256,3 +256,53 @@ def test_first_generation_kernels_give_the_same_frames(sponza):
         sponza.render(cam, va.make_opts(seed=1, pipeline=2))
     with pytest.raises(va.VmxError, match="A/B library"):
         sponza.render(cam, va.make_opts(seed=1, early_stop=False, reorder=0x35, tail_threshold=1))
+
+
+def test_threads_render_and_introspect_concurrently():
+    """The ABI is blocking and a scene serialises its own calls (vmx_scene::mu); different scenes may be driven from
+    different host threads at the same time, and vmx_scene_describe / _timings / _bvh may be called while another
+    thread renders on the same scene (flat_ready is atomic, timings are copied under the lock)."""
+    import threading
+    pos, nrm, uv = scenes.bunny70k()
+    c = scenes.bunny_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 192, 128, 32, back_size=(3.6, 2.4))
+    opts = va.make_opts(seed=6, early_stop=True)
+    with va.Scene(pos, nrm, uv) as ref_sc:
+        ref, _ = ref_sc.render(cam, opts)
+    scs = [va.Scene(pos, nrm, uv, builder=b) for b in (va._lib.VMX_BVH_REFERENCE, va._lib.VMX_BVH_REFERENCE,
+                                                       va._lib.VMX_BVH_LBVH, va._lib.VMX_BVH_PLOC)]
+    out, errs, stop = {}, [], threading.Event()
+
+    def render(i):
+        try:
+            for _ in range(6):
+                out[i], _ = scs[i].render(cam, opts)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    def poke():
+        try:
+            while not stop.is_set():
+                for sc in scs:
+                    d = sc.describe()
+                    assert d["ntris"] == pos.shape[0] and d["n_nodes"] > 0
+                    sc.timings()
+                scs[2].bvh()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=render, args=(i,)) for i in range(4)] + [threading.Thread(target=poke)]
+    for t in th:
+        t.start()
+    for t in th[:4]:
+        t.join()
+    stop.set()
+    th[4].join()
+    assert not errs, errs
+    assert np.array_equal(bits(out[0]), bits(ref)) and np.array_equal(bits(out[1]), bits(ref))
+    # device-built trees: their own (deterministic) frames, the same every time
+    for i in (2, 3):
+        again, _ = scs[i].render(cam, opts)
+        assert np.array_equal(bits(out[i]), bits(again))
+    for sc in scs:
+        sc.close()
