@@ -92,3 +92,23 @@ def test_bruteforce_argument_checks():
             sc.render_bruteforce(va.make_camera(cc["position"], cc["rotation_deg"], 16, 8, 70000), va.make_opts())
         with pytest.raises(va.VmxError):
             sc.render_bruteforce(va.make_camera(cc["position"], cc["rotation_deg"], 16, 8, 8), va.make_opts(), flags=6)
+
+
+def test_bruteforce_probe_asks_the_spheres_before_the_tree():
+    """Round 3: the mirror probe's RayCast (integrators.cpp:121) is only asked whether it hit, so the kernel asks the sphere
+    table first and walks the BVH only for probes that hit no sphere.  A partial table (two lights and the floor) makes
+    both routes decide pixels of the same frame: probes going down hit the floor sphere, the others only the mesh, or
+    nothing."""
+    pos, nrm, uv = scenes.bunny70k()
+    some = va.spheres_array([
+        dict(centre=(15, 140, 25), radius=3.5, colour=(0, 7.5, 15), emit=True, normal_centre=(-55, 350, -150), normal_sign=-1),
+        dict(centre=(0, 3300, 1300), radius=250, colour=(15.2, 15.2, 15.2), emit=True, normal_centre=(500, 800, 1300)),
+        dict(centre=(0, -5e7, 0), radius=5e7)])
+    g, c = va.Scene(pos, nrm, uv, spheres=some), O.OracleScene(pos, nrm, uv, spheres=some)
+    cc = scenes.bunny_camera()
+    cam = va.make_camera(cc["position"], cc["rotation_deg"], 192, 128, 32, back_size=(3.6, 2.4))
+    img, st = g.render_bruteforce(cam, va.make_opts(seed=21))
+    ref, rst = c.render_bruteforce(cam, va.make_opts(seed=21))
+    assert same(img, ref) and st["samples"] == rst["samples"] and st["rays_secondary"] == rst["rays_secondary"]
+    assert 0.0 < img[:, :, 3].min() < 1.0 or np.isinf(img[:, :, 4]).any()  # some camera rays leave the scene
+    g.close(), c.close()

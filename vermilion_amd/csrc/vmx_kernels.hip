@@ -2604,9 +2604,24 @@ __device__ __forceinline__ BfSample bf_sample(const SceneDev &sc, const FrameDev
         const float k = dot3(nx, ny, nz, mLx, mLy, mLz);
         const float sx = mLx - (2.f * nx) * k, sy = mLy - (2.f * ny) * k, sz = mLz - (2.f * nz) * k;
         if (finite3(sx, sy, sz)) r.flags |= 4u;
-        CastResult c2;
-        ray_cast<false>(sc, hx, hy, hz, sx, sy, sz, stk, c2, cnt, ovf, lds_entries);  // :121
-        if (!(c2.nearest < kInf)) {                                  // :133-137
+        // :121 — the probe's RayCast is only asked WHETHER it hit (:133).  RayCast returns nearest < INFINITY
+        // (meshEngine.cpp:508), which is true iff the BVH query hit or some sphere of the table gave 0 < t < inf
+        // (:378 with nearest still infinite) — whatever the order.  The spheres are asked first: inside the reference's
+        // room (six 5e7-radius wall spheres) every probe with a finite direction hits one, and the BVH traversal —
+        // half of this integrator's rays, the incoherent half — is only run for the probes that hit no sphere.
+        bool probe_hit = false;
+        for (uint32_t i = 0; i < sc.nspheres && !probe_hit; ++i) {
+            const SphereDev &q = sc.spheres[i];
+            const float th = sphere_hit(hx, hy, hz, sx, sy, sz, make_float4(q.cx, q.cy, q.cz, q.rad2), kInf);
+            probe_hit = th > 0.f && th < kInf;
+        }
+        if (!probe_hit) {
+            float best2;
+            int slot2;
+            bvh_nearest<false>(sc, hx, hy, hz, sx, sy, sz, stk, best2, slot2, cnt, ovf, lds_entries);
+            probe_hit = slot2 >= 0;
+        }
+        if (!probe_hit) {                                            // :133-137
             vNDL = vNDL * 0.9f;
             vNDL = vNDL + 0.1f;
         }
