@@ -55,6 +55,17 @@ extern "C" {
  * widened argument, narrowed to float.  The two readings differ in the last bit for ~1.3 % of the arguments
  * (uniform in [0, 2 pi)); of 10^6 paths' radiance none differed (tests/test_oracle.py). */
 #define VMX_SAMPLING_LIBM_DOUBLE 0x100u
+/* Flag, OR-ed into vmx_opts.sampling; OFF by default.  Under the reference's sampling (r2 = 10 U, pathtracer.cpp:156,170)
+ * nine in ten diffuse bounces produce a NaN direction and end the path, and a path that ends at
+ * its first hit returns exactly (0,0,0) unless that hit — or a nearer-so-far test on the way (meshEngine.cpp:377-420) — is
+ * a light sphere.  Whether a camera path ends there is decided by its own random draws alone (the specular test :98 and
+ * r2 :156 / :170, for both values of the material flag), and whether a light sphere can colour it by the ray alone.
+ * With this flag such paths are not traced at all: the frame is bit-identical (Camera::mImage holds r,g,b and the sample
+ * count, camera.cpp:106-113 — the primary hit distance Radiance also returns, :44-47, is not part of it), but
+ * vmx_stats.rays_primary counts only the rays that were traced, so throughput figures are not comparable with the
+ * default.  Applies to the split-wavefront passes of vmx_render* (not to vmx_radiance, whose output includes that
+ * distance).  With VMX_SAMPLING_CORRECTED almost no path ends at its first hit and the flag changes little. */
+#define VMX_SAMPLING_ELIDE_DEAD 0x200u
 
 /*
  * One analytic sphere of MeshEngine::RayCast's hard-coded table
@@ -93,7 +104,7 @@ typedef struct vmx_opts {
     uint64_t seed;         /* the reference seeds from std::random_device (pathtracer.cpp:231);
                               here the stream of sample k of pixel p is keyed by (seed, p, k) */
     uint32_t early_stop;   /* 1: reference early-stop rule (pathtracer.cpp:290-311); 0: fixed spp */
-    uint32_t sampling;     /* VMX_SAMPLING_PARITY / _CORRECTED, | VMX_SAMPLING_LIBM_DOUBLE */
+    uint32_t sampling;     /* VMX_SAMPLING_PARITY / _CORRECTED, | VMX_SAMPLING_LIBM_DOUBLE | VMX_SAMPLING_ELIDE_DEAD */
     uint32_t rank;         /* image-stripe sharding: this call renders the stripes s   */
     uint32_t world;        /*   with s % world == rank; world 0 or 1 = whole image     */
     uint32_t stripe_rows;  /* rows per stripe; 0 -> 16                         */

@@ -152,7 +152,8 @@ def test_radiance_paths_bit_exact(pair, sampling, form):
 
 
 @pytest.mark.parametrize("form", PRODUCTION_FORMS, ids=FORM_IDS)
-@pytest.mark.parametrize("early_stop,sampling", [(1, 0), (0, 0), (1, 1), (0, 1), (0, 0x100), (1, 0x101)])
+# 0x200: VMX_SAMPLING_ELIDE_DEAD — camera paths whose radiance is provably zero are not traced; the frame is the same
+@pytest.mark.parametrize("early_stop,sampling", [(1, 0), (0, 0), (1, 1), (0, 1), (0, 0x100), (1, 0x101), (1, 0x200), (0, 0x200), (0, 0x201), (1, 0x300)])
 def test_frame_bit_exact(pair, early_stop, sampling, form):
     c = pair.camf()
     W, H, spp = (160, 96, 16) if pair.name in ("bunny70k", "sponza260k") else (128, 128, 16)
@@ -164,7 +165,15 @@ def test_frame_bit_exact(pair, early_stop, sampling, form):
     ref, rst = pair.cpu.render(cam, opts)
     assert img.shape == (H, W, 5)
     assert np.array_equal(bits(img), bits(ref)), f"{int((bits(img) != bits(ref)).any(axis=2).sum())} pixels differ"
-    if st["samples_discarded"] == 0:
+    if sampling & va.VMX_SAMPLING_ELIDE_DEAD:
+        # rays_primary counts the camera rays that were traced; every path that goes on was traced
+        assert st["rays_primary"] <= rst["rays_primary"] + st["samples_discarded"]
+        assert st["rays_secondary"] >= rst["rays_secondary"]
+        if st["samples_discarded"] == 0:
+            assert st["rays_secondary"] == rst["rays_secondary"]
+        if form.get("pipeline") == 4 and (sampling & 0xFF) == 0:
+            assert st["rays_primary"] < 0.5 * rst["rays_primary"]  # r2 = 10 U: ~2 in 3 camera paths end black at their first hit
+    elif st["samples_discarded"] == 0:
         assert st["rays_primary"] == rst["rays_primary"] and st["rays_secondary"] == rst["rays_secondary"]
     else:  # speculative samples that an early stop discarded were traced too
         assert st["rays_primary"] == rst["rays_primary"] + st["samples_discarded"]
@@ -358,6 +367,14 @@ def test_custom_sphere_tables():
             if st["samples_discarded"] == 0:
                 assert st["rays_secondary"] == rst["rays_secondary"]
             assert st["samples"] == rst["samples"]
+            # VMX_SAMPLING_ELIDE_DEAD with light spheres in view (split passes): paths that may reach one are traced
+            for es in (False, True):
+                o2 = va.make_opts(seed=21, sampling=sampling, early_stop=es, pipeline=4)
+                o3 = va.make_opts(seed=21, sampling=sampling | va.VMX_SAMPLING_ELIDE_DEAD, early_stop=es, pipeline=4)
+                ref2 = ref if es else p.cpu.render(cam, o2)[0]
+                img3, st3 = p.gpu.render(cam, o3)
+                assert np.array_equal(bits(img3), bits(ref2)), (sampling, es)
+                assert st3["rays_primary"] <= p.gpu.render(cam, o2)[1]["rays_primary"]
         if n:
             assert img[:, :, :3].mean() > 0.01  # the area light actually lights the set
         p.close()
@@ -501,7 +518,8 @@ def test_textured_paths_bit_exact_f2(channels, size):
         assert np.array_equal(bits(rad), bits(rrad))
         for es in (0, 1):
             for pipeline in (0, 1, 4):
-                o2 = va.make_opts(seed=31, sampling=sampling, early_stop=bool(es), pipeline=pipeline, max_paths=40000)
+                o2 = va.make_opts(seed=31, sampling=sampling | (va.VMX_SAMPLING_ELIDE_DEAD if pipeline == 4 and es else 0),
+                                  early_stop=bool(es), pipeline=pipeline, max_paths=40000)
                 img, _ = p.gpu.render(cam, o2)
                 if pipeline == 0:
                     ref, _ = p.cpu.render(cam, o2)

@@ -6,7 +6,7 @@ the reference's Integrator plugin surface plus synthetic scene generators.
 Importing `vermilion_amd` does not need a GPU; creating a Scene does.
 """
 from . import _lib
-from ._lib import (VMX_SAMPLING_CORRECTED, VMX_SAMPLING_LIBM_DOUBLE, VMX_SAMPLING_PARITY, VmxError)
+from ._lib import (VMX_SAMPLING_CORRECTED, VMX_SAMPLING_ELIDE_DEAD, VMX_SAMPLING_LIBM_DOUBLE, VMX_SAMPLING_PARITY, VmxError)
 from .scene import (MultiScene, Scene, default_spheres, local_row_indices, local_rows, make_camera, make_opts,
                     spheres_array)
 from .api import (Camera, Integrator, MeshEngine, PathTracer, RenderEngine, cameraSettings, float3,
@@ -17,5 +17,5 @@ __all__ = [
     "Scene", "MultiScene", "make_camera", "make_opts", "spheres_array", "default_spheres", "local_rows",
     "local_row_indices", "Camera", "Integrator", "MeshEngine", "PathTracer", "RenderEngine",
     "cameraSettings", "float3", "pixelValue", "vermRenderMode", "scenes", "VmxError",
-    "VMX_SAMPLING_PARITY", "VMX_SAMPLING_CORRECTED", "VMX_SAMPLING_LIBM_DOUBLE",
+    "VMX_SAMPLING_PARITY", "VMX_SAMPLING_CORRECTED", "VMX_SAMPLING_LIBM_DOUBLE", "VMX_SAMPLING_ELIDE_DEAD",
 ]

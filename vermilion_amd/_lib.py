@@ -21,6 +21,7 @@ VMX_SPHERE_EMIT = 1
 VMX_SAMPLING_PARITY = 0
 VMX_SAMPLING_CORRECTED = 1
 VMX_SAMPLING_LIBM_DOUBLE = 0x100
+VMX_SAMPLING_ELIDE_DEAD = 0x200
 VMX_BVH_REFERENCE = 0
 VMX_BVH_SAH = 1
 VMX_BVH_LBVH = 2

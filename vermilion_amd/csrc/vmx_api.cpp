@@ -123,6 +123,10 @@ struct Workspace {
     DevBuf<unsigned char> cam_inner;                    // per-frame camera-relative scene tables: 8 node copies, then the triangles
     DevBuf<unsigned char> rad;          // float4 per path of a pass
     DevBuf<unsigned long long> rad_mask;  // split pipeline: one bit per path, "its radiance was stored" (PathArrays::rad_mask)
+    // VMX_SAMPLING_ELIDE_DEAD: live bits per 64 paths; [popcounts | their exclusive scan | list length]; the list; scan scratch
+    DevBuf<unsigned long long> live_mask;
+    DevBuf<unsigned int> live_u32, live_ids;
+    DevBuf<unsigned char> live_tmp;
     DevBuf<unsigned char> accum;        // float4 per local pixel
     DevBuf<unsigned int> count, cursor, active[2], next_count;
     DevBuf<DevCounters> counters;
@@ -137,6 +141,7 @@ struct Workspace {
         sort_keys[0].release(), sort_keys[1].release(), ids_sorted.release(), sort_tmp.release();
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
+        live_mask.release(), live_u32.release(), live_ids.release(), live_tmp.release();
     }
 };
 
@@ -214,7 +219,7 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
     if (spp < 4)
         return fail(VMX_ERR_INVALID,
                     "rays_per_pixel < 4 renders no sample (uSamplesPerPixel/4 == 0, pathtracer.cpp:247)");
-    if ((o.sampling & VMX_SAMPLING_MODE_MASK) > VMX_SAMPLING_CORRECTED || (o.sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE)))
+    if ((o.sampling & VMX_SAMPLING_MODE_MASK) > VMX_SAMPLING_CORRECTED || (o.sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE | VMX_SAMPLING_ELIDE_DEAD)))
         return fail(VMX_ERR_INVALID, "unknown sampling mode");
     const float rx = (float)(-cam.rotation_deg[0] * 3.1415926535 / 180);
     const float ry = (float)(-cam.rotation_deg[1] * 3.1415926535 / 180);
@@ -234,6 +239,7 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
     fr.early_stop = o.early_stop ? 1u : 0u;
     fr.r2scale = (o.sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
     fr.libm_double = (o.sampling & VMX_SAMPLING_LIBM_DOUBLE) ? 1u : 0u;
+    fr.elide_dead = (o.sampling & VMX_SAMPLING_ELIDE_DEAD) ? 1u : 0u;  // split passes of vmx_render only (k_raygen)
     fr.world = o.world <= 1 ? 1u : o.world;
     fr.rank = o.world <= 1 ? 0u : o.rank;
     fr.stripe_rows = o.stripe_rows ? o.stripe_rows : 16u;
@@ -623,7 +629,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     uint64_t mem_budget = 0;
     const size_t n_pad_cap = ((size_t)npix + 63u) & ~(size_t)63u;
     if (!opts->samples_per_batch && !legacy) {
-        const size_t per_path = 16 + 64 + 8 + 16 + 8 + (sc->dev.tex ? 16 : 0) + (tn.sort_mode ? 12 : 0);
+        const size_t per_path = 16 + 64 + 8 + 16 + 8 + (sc->dev.tex ? 16 : 0) + (tn.sort_mode ? 12 : 0) + (fr.elide_dead ? 5 : 0);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const size_t held = ws.rayA.n + ws.state.n + ws.hit.n + ws.rad.n + ws.thr.n + (ws.ids[0].n + ws.ids[1].n) * 4 +
@@ -688,6 +694,15 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     if (ws.heads.ensure(kSubQueues * 32)) return fail(VMX_ERR_NOMEM, "work heads");
     if (ws.rad_mask.ensure(((size_t)n_pad_max * smax + 63) / 64 + 8)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the radiance mask");
     if (split_any) pa.rad_mask = ws.rad_mask.p;
+    const bool elide = split_any && fr.elide_dead && !count;  // (the counting build traces every path: its totals are the oracle's)
+    const size_t live_words_max = ((size_t)n_pad_max * smax + 63) / 64;
+    size_t live_tmp_bytes = 0;
+    if (elide) {
+        live_tmp_bytes = live_compact_tmp_bytes((uint32_t)live_words_max);
+        if (ws.live_mask.ensure(live_words_max + 8) || ws.live_u32.ensure(2 * live_words_max + 16) ||
+            ws.live_ids.ensure((size_t)n_pad_max * smax + 64) || ws.live_tmp.ensure(live_tmp_bytes + 256))
+            return fail(VMX_ERR_NOMEM, "hipMalloc failed for the live-path list");
+    }
     if (ws.rad.ensure((size_t)n_pad_max * smax * 16) || ws.accum.ensure((size_t)npix * 16) ||
         ws.count.ensure(npix) || ws.cursor.ensure(npix) || ws.active[0].ensure(npix) ||
         ws.active[1].ensure(npix) || ws.next_count.ensure(32) || ws.counters.ensure(1))
@@ -803,7 +818,19 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             TimedLaunch tg{ws.events.get(), ws.events.get(), -1, VMX_K_RAYGEN};
             if (!tg.a || !tg.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(tg.a, s));
-            LAUNCH_TRY(launch_raygen(fr, wk, px, pa, s));
+            if (elide) {
+                // live bits -> ordered list of live path ids -> their rays, dense; trace and shade then work on the list
+                const uint32_t nwords = (uint32_t)(((uint64_t)n_pad * S + 63) / 64);
+                unsigned int *cnt = ws.live_u32.p, *offs = cnt + live_words_max, *len = offs + live_words_max;
+                wk.live_mask = ws.live_mask.p, wk.live_cnt = cnt;
+                LAUNCH_TRY(launch_raygen(sc->dev, fr, wk, px, pa, s));
+                HIP_TRY((hipError_t)launch_live_compact(ws.live_mask.p, cnt, nwords, offs, ws.live_ids.p, len, ws.live_tmp.p, live_tmp_bytes, s));
+                wk.live_ids = ws.live_ids.p, wk.live_count = len;
+                LAUNCH_TRY(launch_raygen_live(fr, wk, px, pa, s));
+                HIP_TRY(hipMemsetAsync(pa.rad_mask, 0, (size_t)nwords * 8, s));
+            } else {
+                LAUNCH_TRY(launch_raygen(sc->dev, fr, wk, px, pa, s));
+            }
             HIP_TRY(hipEventRecord(tg.b, s));
             timed.push_back(tg);
             HIP_TRY(hipEventRecord(tl.a, s));
@@ -1206,7 +1233,7 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     vmx_scene *sc = const_cast<vmx_scene *>(csc);
     if (!sc || !origin || !dir || !opts || !out) return fail(VMX_ERR_INVALID, "NULL argument");
     if ((opts->sampling & VMX_SAMPLING_MODE_MASK) > VMX_SAMPLING_CORRECTED ||
-        (opts->sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE)))
+        (opts->sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE | VMX_SAMPLING_ELIDE_DEAD)))
         return fail(VMX_ERR_INVALID, "unknown sampling mode");
     if (opts->reserved[0] > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
 #ifdef VMX_AB_KERNELS
@@ -1231,6 +1258,7 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     std::memset(&fr, 0, sizeof(fr));
     fr.r2scale = (opts->sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
     fr.libm_double = (opts->sampling & VMX_SAMPLING_LIBM_DOUBLE) ? 1u : 0u;
+    fr.elide_dead = 0;
     PathArrays pa{};
     IdQueue qi[2];
     int tb = 1, rb = 1;

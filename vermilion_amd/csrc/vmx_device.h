@@ -102,6 +102,7 @@ struct FrameDev {
                                   // paths j >= lead the first samples of the following strata (sample_index)
     float r2scale;                // 10 (parity) or 1 (corrected)
     uint32_t libm_double;         // VMX_SAMPLING_LIBM_DOUBLE: cos/sin(float r1) of pathtracer.cpp:162 as C's double functions
+    uint32_t elide_dead;          // VMX_SAMPLING_ELIDE_DEAD: camera paths with provably zero radiance are not traced
     uint32_t local_rows;          // rows owned by this rank
     uint32_t stripe_rows, rank, world;
     uint64_t seed;

@@ -66,6 +66,14 @@ struct WorkDev {
     uint32_t pixel_major;       // 1: pid = slot * samples + j (samples of a pixel contiguous); 0: j * n_pad + slot
     // queue source
     IdQueue qids;     // k_trace_w / k_trace_q / k_shade / tail (path ids)
+    // VMX_SAMPLING_ELIDE_DEAD: camera paths whose radiance is provably zero are not traced.  k_raygen<1> leaves one word
+    // of live bits + its popcount per 64 path ids; launch_live_compact turns them into the ordered list of live path ids;
+    // k_raygen_live writes their rays to rayA[list position], k_trace_w<0> the hit records to hit[list position], and
+    // k_shade<0> walks the list (NULL: every path of the pass, rayA / hit indexed by path id)
+    unsigned long long *live_mask;
+    unsigned int *live_cnt;
+    const unsigned int *live_ids;
+    const unsigned int *live_count;  // device scalar: entries of live_ids
     // camera rays: per-frame origin-relative node / triangle tables (k_camera_tables)
     const void *cam_inner;  // float4[8 * n_inner * 4]: one copy per direction octant, octant 0 = plain (lo, hi)
     uint32_t cam_n_inner;   // records per copy
@@ -114,7 +122,11 @@ int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, in
 // split wavefront: persistent trace kernel (per-lane refill) ...
 int launch_camera_tables(const SceneDev &sc, uint32_t n_inner, float ox, float oy, float oz, void *cam_inner,
                          void *cam_tris, void *stream);
-int launch_raygen(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
+int launch_raygen(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
+int launch_raygen_live(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
+size_t live_compact_tmp_bytes(uint32_t nwords);
+int launch_live_compact(const unsigned long long *live_mask, const unsigned int *live_cnt, uint32_t nwords,
+                        unsigned int *offs, unsigned int *ids, unsigned int *count, void *tmp, size_t tmp_bytes, void *stream);
 int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                    DevCounters *counters, bool count, bool from_queue, LaunchCfg cfg, void *stream);
 int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, bool from_queue, int *blocks);

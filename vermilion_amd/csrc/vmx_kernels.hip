@@ -1346,8 +1346,35 @@ __global__ void k_camera_tables(SceneDev sc, uint32_t n_inner, float ox, float o
 // (direction, depth flag): all camera rays share the frame's origin, so 16 bytes per ray suffice.
 // Slots whose sample index is past the pixel's last sample get depth = ~0 and are skipped downstream.
 // ---------------------------------------------------------------------------
+// VMX_SAMPLING_ELIDE_DEAD: is the radiance of this camera path provably (0,0,0)?  `rng` is the path's stream after the
+// two jitter draws.  A path that ends at its first hit returns accumColour = hitColour (pathtracer.cpp:43), which only a
+// light sphere sets (meshEngine.cpp:382-383,415-416).  It ends there, whatever it hits, iff its own draws say so for BOTH
+// values of the material flag: material (:98-165): not the mirror branch (draw 1 < 0.96) and r2 = float(10 * draw 3) > 1,
+// so sqrt(1 - r2) is NaN; no material (:166-196): r2 = 10 * draw 2 > 1 (double).  (No Russian-roulette draw at depth 0;
+// a miss returns the same zero.)  And no light sphere can colour it iff sphereIntersect is 0 for every emitting sphere —
+// the reference's own arithmetic with nothing nearer yet (limit = infinity).
+__device__ __forceinline__ bool camera_path_is_dead(const SceneDev &sc, const FrameDev &fr, Rng rng, float dx, float dy, float dz) {
+    const double a = rng_u01(rng), b = rng_u01(rng), c = rng_u01(rng);
+    const float r2m = (float)((double)fr.r2scale * c);
+    const bool ends_mat = !(a >= 0.96) && (1.0f - r2m) < 0.0f;
+    const bool ends_nomat = (1.0 - (double)fr.r2scale * b) < 0.0;
+    bool dead = ends_mat && ends_nomat;
+    for (uint32_t i = 0; i < sc.nspheres; ++i) {
+        const SphereDev &q = sc.spheres[i];
+        if ((q.flags & 1u) && __builtin_amdgcn_ballot_w64(dead) != 0) {
+            const float th = sphere_hit(fr.px, fr.py, fr.pz, dx, dy, dz, make_float4(q.cx, q.cy, q.cz, q.rad2), kInf);
+            if (th > 0.f) dead = false;
+        }
+    }
+    return dead;
+}
+
+// LIVE 0: every camera ray of the pass, rayA[pid].   LIVE 1 (VMX_SAMPLING_ELIDE_DEAD): nothing is written but one word
+// of live bits and its popcount per 64 consecutive path ids; launch_live_compact turns those into the ordered list of
+// live path ids and k_raygen_live writes their rays, densely, to rayA[position in that list].
+template <int LIVE>
 __global__ void __launch_bounds__(256)
-k_raygen(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
+k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
     const uint32_t total = wk.samples * wk.n_pad;
     if (wk.pixel_major && (wk.samples & 63u) == 0) {
         // a wave's 64 path ids are 64 samples of ONE pixel: slot, pixel and cursor are wave-uniform — one division and one
@@ -1357,37 +1384,74 @@ k_raygen(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
         for (uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
              w * 64u < total; w += waves) {
             const uint32_t pid0 = w * 64u, s_idx = pid0 / wk.samples, j = pid0 - s_idx * wk.samples + lane;
-            if (s_idx >= wk.n_active) continue;
-            const uint32_t lp = wk.active[s_idx];
-            const uint32_t k = sample_index(fr, px, lp, j);
-            float dx = 0.f, dy = 0.f, dz = 0.f;
-            uint32_t depth = 0xFFFFFFFFu;
-            if (k < fr.kmax) {
-                Rng rng;
-                primary_ray(fr, global_pixel(fr, lp), k, rng, dx, dy, dz);
-                depth = 0;
+            bool live = false;
+            if (s_idx < wk.n_active) {
+                const uint32_t lp = wk.active[s_idx];
+                const uint32_t k = sample_index(fr, px, lp, j);
+                float dx = 0.f, dy = 0.f, dz = 0.f;
+                uint32_t depth = 0xFFFFFFFFu;
+                if (k < fr.kmax) {
+                    Rng rng;
+                    primary_ray(fr, global_pixel(fr, lp), k, rng, dx, dy, dz);
+                    depth = 0;
+                    if (LIVE) live = !camera_path_is_dead(sc, fr, rng, dx, dy, dz);
+                }
+                if (!LIVE) ((float4 *)pa.rayA)[pid0 + lane] = make_float4(dx, dy, dz, __uint_as_float(depth));
             }
-            ((float4 *)pa.rayA)[pid0 + lane] = make_float4(dx, dy, dz, __uint_as_float(depth));
+            if (LIVE) {
+                const unsigned long long bits = __builtin_amdgcn_ballot_w64(live);
+                if (lane == 0) wk.live_mask[w] = bits, wk.live_cnt[w] = (uint32_t)__popcll(bits);
+            }
         }
         return;
     }
+    // (n_pad, and with it total, is a multiple of 64: a wave's 64 lanes hold 64 consecutive path ids and run the body together)
     for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < total; pid += gridDim.x * blockDim.x) {
         uint32_t j, s_idx;
         if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
         else j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
-        if (s_idx >= wk.n_active) continue;
         uint32_t pid2, pixel, k;
         float dx = 0.f, dy = 0.f, dz = 0.f;
         uint32_t depth = 0xFFFFFFFFu;
-        if (primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {
+        bool live = false;
+        if (s_idx < wk.n_active && primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {
+            Rng rng;
+            primary_ray(fr, pixel, k, rng, dx, dy, dz);
+            depth = 0;
+            if (LIVE) live = !camera_path_is_dead(sc, fr, rng, dx, dy, dz);
+        }
+        // camera rays share the origin (FrameDev): one 16-byte record (direction, depth flag) in rayA
+        if (!LIVE && s_idx < wk.n_active) ((float4 *)pa.rayA)[pid] = make_float4(dx, dy, dz, __uint_as_float(depth));
+        if (LIVE) {
+            const unsigned long long bits = __builtin_amdgcn_ballot_w64(live);
+            if ((threadIdx.x & 63u) == 0) wk.live_mask[pid >> 6] = bits, wk.live_cnt[pid >> 6] = (uint32_t)__popcll(bits);
+        }
+    }
+}
+
+// the rays of the live camera paths, in list order: rayA[i] belongs to path live_ids[i]
+__global__ void __launch_bounds__(256)
+k_raygen_live(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
+    const uint32_t n = *wk.live_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t pid = wk.live_ids[i];
+        uint32_t j, s_idx;
+        if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
+        else j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
+        uint32_t pid2, pixel, k;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        uint32_t depth = 0xFFFFFFFFu;
+        if (primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {  // (always: the path was found live from the same item)
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
             depth = 0;
         }
-        // camera rays share the origin (FrameDev): one 16-byte record (direction, depth flag) in rayA
-        ((float4 *)pa.rayA)[pid] = make_float4(dx, dy, dz, __uint_as_float(depth));
+        ((float4 *)pa.rayA)[i] = make_float4(dx, dy, dz, __uint_as_float(depth));
     }
 }
+
+// VMX_SAMPLING_ELIDE_DEAD: the n live camera paths of a pass are split into 8 bands of whole waves, one per work source
+__device__ __forceinline__ uint32_t live_band(uint32_t n) { return ((n + 511u) / 512u) * 64u; }
 
 // ---------------------------------------------------------------------------
 // k_trace_q — the first form of the split wavefront's persistent traversal kernel
@@ -1435,7 +1499,11 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= refill_min || idle == ~0ull)) {
             for (;;) {
                 if (res_lo == res_hi) {
-                    const uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
+                    uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
+                    if (SRC == 0 && wk.live_ids) {  // (scalar loads, once per reservation)
+                        const uint32_t n = *wk.live_count, seg = live_band(n);
+                        lim = min(seg, n - min(n, src * seg));
+                    }
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&wk.heads[src * 32], kReserve);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -1471,6 +1539,8 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                         }
                         valid = s_idx < wk.n_active;
                         pid = path_id(wk, j, s_idx);
+                        // VMX_SAMPLING_ELIDE_DEAD: the live camera paths, dense in list order (ray and hit record at the list position)
+                        if (wk.live_ids) valid = true, pid = src * live_band(*wk.live_count) + item;
                     } else {
                         pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
                     }
@@ -2135,7 +2205,11 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= refill_min || idle == ~0ull)) {
             for (;;) {
                 if (res_lo == res_hi) {
-                    const uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
+                    uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
+                    if (SRC == 0 && wk.live_ids) {  // (scalar loads, once per reservation)
+                        const uint32_t n = *wk.live_count, seg = live_band(n);
+                        lim = min(seg, n - min(n, src * seg));
+                    }
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&wk.heads[src * 32], kReserve);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -2170,6 +2244,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                         }
                         valid = s_idx < wk.n_active;
                         pid = path_id(wk, j, s_idx);
+                        // VMX_SAMPLING_ELIDE_DEAD: the live camera paths, dense in list order (ray and hit record at the list position)
+                        if (wk.live_ids) valid = true, pid = src * live_band(*wk.live_count) + item;
                     } else {
                         pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
                     }
@@ -2302,13 +2378,18 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
     }
     __syncthreads();
     Tally tl = {{0, 0}, {0, 0}, {0, 0}};
-    const uint32_t items = SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues;
+    uint32_t items = SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues;
+    // VMX_SAMPLING_ELIDE_DEAD: the pass's live camera paths only; ray and hit record sit at the list position `src`
+    const bool listed = SRC == 0 && wk.live_ids != nullptr;
+    uint32_t live_n = 0;
+    if (listed) live_n = *wk.live_count, items = (live_n + blockDim.x - 1) / blockDim.x;
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
         bool run;
-        uint32_t pid = 0;
+        uint32_t pid = 0, src = 0;
         Path P;
         if (SRC == 0) {
-            pid = item * blockDim.x + threadIdx.x;
+            src = pid = item * blockDim.x + threadIdx.x;
+            if (listed) pid = src < live_n ? wk.live_ids[src] : 0xFFFFFFFFu;  // (no such path: j >= samples below)
             uint32_t j, s_idx;
             if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
             else j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
@@ -2316,7 +2397,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             run = j < wk.samples && s_idx < wk.n_pad && primary_item(fr, wk, px, j, s_idx, pid2, pixel, k);
             if (run) {
                 // the ray comes from k_raygen; the stream is re-keyed and its two jitter draws skipped
-                const float4 a = ((const float4 *)pa.rayA)[pid];
+                const float4 a = ((const float4 *)pa.rayA)[src];
                 P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz, P.dx = a.x, P.dy = a.y, P.dz = a.z, P.depth = 0;
                 rng_init(P.rng, fr.seed, pixel, k);
                 (void)rng_next(P.rng);
@@ -2343,7 +2424,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             P.dest = pid;
             depth0 = P.depth == 0 ? 1u : 0u;
             fl.was_ray = depth0 ? true : finite3(P.dx, P.dy, P.dz);
-            const float2 h = hits[pid];
+            const float2 h = hits[SRC == 0 ? src : pid];
             cast_finish<true, SRC == 0>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom,
                                         s_cam_op);
             st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
@@ -2368,8 +2449,12 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             // aligned word of the mask (path ids of an item are consecutive, 256 per block)
             const bool need = run && (alive || P.ar != 0.f || P.ag != 0.f || P.ab != 0.f);
             if (need) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
-            const unsigned long long word = __builtin_amdgcn_ballot_w64(need);
-            if ((threadIdx.x & 63u) == 0) pa.rad_mask[(item * blockDim.x + threadIdx.x) >> 6] = word;
+            if (listed) {  // the mask was cleared for the pass; the list's neighbours share words
+                if (need) atomicOr(&pa.rad_mask[pid >> 6], 1ull << (pid & 63u));
+            } else {
+                const unsigned long long word = __builtin_amdgcn_ballot_w64(need);
+                if ((threadIdx.x & 63u) == 0) pa.rad_mask[(item * blockDim.x + threadIdx.x) >> 6] = word;
+            }
         }
         tally_add(tl, fl, run, depth0);
         id_append(qout, item % kSubQueues, alive, pid);
@@ -2889,11 +2974,21 @@ int launch_camera_tables(const SceneDev &sc, uint32_t n_inner, float ox, float o
     return launch_status();
 }
 
-int launch_raygen(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream) {
+int launch_raygen(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream) {
     const uint64_t total = (uint64_t)wk.samples * wk.n_pad;
     uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 32u);
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(256), 0, (hipStream_t)stream, fr, wk, px, pa);
+    if (wk.live_mask) hipLaunchKernelGGL(k_raygen<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sc, fr, wk, px, pa);
+    else hipLaunchKernelGGL(k_raygen<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, sc, fr, wk, px, pa);
+    return launch_status();
+}
+
+int launch_raygen_live(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream) {
+    // the list's length is known on the device only: a grid for a third of the pass's paths, striding over the rest
+    const uint64_t total = ((uint64_t)wk.samples * wk.n_pad + 2) / 3;
+    uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 32u);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_raygen_live, dim3(grid), dim3(256), 0, (hipStream_t)stream, fr, wk, px, pa);
     return launch_status();
 }
 
