@@ -166,13 +166,14 @@ def test_frame_bit_exact(pair, early_stop, sampling, form):
     assert img.shape == (H, W, 5)
     assert np.array_equal(bits(img), bits(ref)), f"{int((bits(img) != bits(ref)).any(axis=2).sum())} pixels differ"
     if sampling & va.VMX_SAMPLING_ELIDE_DEAD:
-        # rays_primary counts the camera rays that were traced; every path that goes on was traced
+        # the counters hold the rays that were traced
         assert st["rays_primary"] <= rst["rays_primary"] + st["samples_discarded"]
-        assert st["rays_secondary"] >= rst["rays_secondary"]
         if st["samples_discarded"] == 0:
-            assert st["rays_secondary"] == rst["rays_secondary"]
-        if form.get("pipeline") == 4 and (sampling & 0xFF) == 0:
-            assert st["rays_primary"] < 0.5 * rst["rays_primary"]  # r2 = 10 U: ~2 in 3 camera paths end black at their first hit
+            assert st["rays_secondary"] <= rst["rays_secondary"]
+        if (sampling & 0xFF) == 0:  # r2 = 10 U: 78 % of all steps are the path's last whatever they hit
+            assert st["rays_primary"] < 0.4 * rst["rays_primary"] and st["rays_secondary"] < 0.4 * rst["rays_secondary"]
+        elif st["samples_discarded"] == 0:  # r2 = U: only Russian roulette (past depth 5) ever ends a path by its draws alone
+            assert st["rays_primary"] == rst["rays_primary"] and st["rays_secondary"] > 0.9 * rst["rays_secondary"]
     elif st["samples_discarded"] == 0:
         assert st["rays_primary"] == rst["rays_primary"] and st["rays_secondary"] == rst["rays_secondary"]
     else:  # speculative samples that an early stop discarded were traced too

@@ -1,6 +1,6 @@
 // path_compact.hip — order-preserving compaction of the camera paths that have to be traced (VMX_SAMPLING_ELIDE_DEAD).
 //
-// k_raygen decides per path whether its radiance is provably zero (vmx_kernels.hip: camera_path_is_dead) and leaves,
+// k_raygen<1> decides per path whether its radiance is provably zero (vmx_kernels.hip: step_is_dead) and leaves,
 // per wave of 64 consecutive path ids, one word of live bits and its popcount.  Here: exclusive scan of the popcounts
 // (hipcub), then every live path id is written to its place — neighbours stay neighbours, so a traversal wave still
 // holds samples of one pixel (or of a few neighbouring ones).

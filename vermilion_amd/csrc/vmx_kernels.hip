@@ -584,6 +584,7 @@ __device__ __forceinline__ float libm_sincosf(float y, int which) {
 struct SampCfg {
     float r2scale;
     uint32_t libm_double;
+    uint32_t elide;  // VMX_SAMPLING_ELIDE_DEAD (step_is_dead)
 };
 
 // The loop body is split where the cosine-lobe branch needs cos/sin of r1 (double precision, a few
@@ -709,16 +710,60 @@ __device__ __forceinline__ bool path_shade_end(Path &P, const CastResult &c, Ste
     return path_set_ray(P, fl, m.sx, m.sy, m.sz, ndx, ndy, ndz);
 }
 
+// VMX_SAMPLING_ELIDE_DEAD: is the Radiance step that would trace this ray provably without effect on the path's colour?
+// `rng`, `depth`, the ray and the throughput are the path's state before that step.  The step adds accumRadiance *
+// hitColour (pathtracer.cpp:43), and hitColour is non-zero only where a light sphere is the hit (meshEngine.cpp:382-383,
+// 415-416); a miss returns accumColour as it is (:36-41).  The step is the path's last one, whatever it hits, iff the
+// path's own draws say so for BOTH values of the material flag:
+//   Russian roulette (:56, past depth 5): its draw > 0.95f, or
+//   material (:98-165): not the mirror branch (next draw < 0.96) and r2 = float(10 * third draw) > 1, so sqrt(1 - r2)
+//     is NaN and with it the next direction, which misses everything and
+//   no material (:166-196): r2 = 10 * second draw > 1 (double), the same.
+// No light sphere can colour it iff sphereIntersect is 0 for every emitting sphere — the reference's own arithmetic with
+// nothing nearer yet (limit = infinity).  Then accumColour after the step equals accumColour before it bit for bit
+// (x + t * 0 == x for finite t), so the ray need not be traced: with the reference's r2 = 10 U that is 78 % of all rays.
+// (Nothing is ever elided under VMX_SAMPLING_CORRECTED: r2 = U never exceeds 1.)
+template <bool TEX, bool LDS_GEOM>
+__device__ __forceinline__ bool step_is_dead(const SceneDev &sc, float r2scale, Rng rng, uint32_t depth, float ox, float oy,
+                                             float oz, float dx, float dy, float dz, float tr, float tg, float tb,
+                                             const float4 *geom = nullptr) {
+    bool rr_end = false;
+    if (depth + 1u > 5u) {
+        const double rr = rng_u01(rng);
+        rr_end = rr > (double)0.95f || depth + 1u > 1000u;
+    }
+    const double a = rng_u01(rng), b = rng_u01(rng), c = rng_u01(rng);
+    const float r2m = (float)((double)r2scale * c);
+    const bool ends_mat = !(a >= 0.96) && (1.0f - r2m) < 0.0f;
+    const bool ends_nomat = (1.0 - (double)r2scale * b) < 0.0;
+    bool dead = rr_end || (ends_mat && ends_nomat);
+    if (TEX && !finite3(tr, tg, tb)) dead = false;  // inf * 0 would be NaN
+    for (uint32_t i = 0; i < sc.nspheres; ++i) {
+        const SphereDev &q = sc.spheres[i];
+        if ((q.flags & 1u) && __builtin_amdgcn_ballot_w64(dead) != 0) {
+            const float4 g = LDS_GEOM ? geom[i] : make_float4(q.cx, q.cy, q.cz, q.rad2);
+            const float th = sphere_hit(ox, oy, oz, dx, dy, dz, g, kInf);
+            if (th > 0.f) dead = false;
+        }
+    }
+    return dead;
+}
+
 // Radiance's loop body after RayCast in one piece (the fused kernels)
-template <bool TEX>
+template <bool TEX, bool LDS_GEOM = false>
 __device__ __forceinline__ bool path_shade(const SceneDev &sc, SampCfg cfg, Path &P, const CastResult &c,
-                                           StepFlags &fl) {
+                                           StepFlags &fl, const float4 *geom = nullptr) {
     ShadeMid m;
     const int st = path_shade_begin<TEX>(sc, cfg.r2scale, P, c, fl, m);
-    if (st != kPathNeedsTrig) return st == kPathNextRay;
-    float sn, cs;
-    shade_trig(m, cfg.libm_double, cs, sn);
-    return path_shade_end(P, c, fl, m, cs, sn);
+    bool alive = st == kPathNextRay;
+    if (st == kPathNeedsTrig) {
+        float sn, cs;
+        shade_trig(m, cfg.libm_double, cs, sn);
+        alive = path_shade_end(P, c, fl, m, cs, sn);
+    }
+    if (cfg.elide && alive && step_is_dead<TEX, LDS_GEOM>(sc, cfg.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb, geom))
+        alive = false, fl.continues = false;
+    return alive;
 }
 
 __device__ __forceinline__ void tally_add(Tally &tl, const StepFlags &fl, bool ran, uint32_t stage_depth0) {
@@ -1121,7 +1166,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, float4 *__restri
                     CastResult c;
                     cast_finish<true, false>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, best, slot, c, s_geom);
                     fl.was_ray = is_ray;
-                    alive = path_shade<TEX>(sc, SampCfg{fr.r2scale, fr.libm_double}, P, c, fl);
+                    alive = path_shade<TEX, true>(sc, SampCfg{fr.r2scale, fr.libm_double, fr.elide_dead}, P, c, fl, s_geom);
                     if (!alive) {
                         rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
                         has = false;
@@ -1183,6 +1228,11 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, float4 *__restri
                                     P.tr = P.tg = P.tb = 1.f;  // :30
                                     P.depth = 0;
                                     P.dest = path_id(wk, j, s_idx);
+                                    if (fr.elide_dead && step_is_dead<false, true>(sc, fr.r2scale, P.rng, 0, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz,
+                                                                                   1.f, 1.f, 1.f, s_geom)) {
+                                        rad[P.dest] = make_float4(0.f, 0.f, 0.f, -100.f);  // untraced: its radiance is zero
+                                        valid = false;
+                                    }
                                 }
                             }
                         } else {
@@ -1346,29 +1396,6 @@ __global__ void k_camera_tables(SceneDev sc, uint32_t n_inner, float ox, float o
 // (direction, depth flag): all camera rays share the frame's origin, so 16 bytes per ray suffice.
 // Slots whose sample index is past the pixel's last sample get depth = ~0 and are skipped downstream.
 // ---------------------------------------------------------------------------
-// VMX_SAMPLING_ELIDE_DEAD: is the radiance of this camera path provably (0,0,0)?  `rng` is the path's stream after the
-// two jitter draws.  A path that ends at its first hit returns accumColour = hitColour (pathtracer.cpp:43), which only a
-// light sphere sets (meshEngine.cpp:382-383,415-416).  It ends there, whatever it hits, iff its own draws say so for BOTH
-// values of the material flag: material (:98-165): not the mirror branch (draw 1 < 0.96) and r2 = float(10 * draw 3) > 1,
-// so sqrt(1 - r2) is NaN; no material (:166-196): r2 = 10 * draw 2 > 1 (double).  (No Russian-roulette draw at depth 0;
-// a miss returns the same zero.)  And no light sphere can colour it iff sphereIntersect is 0 for every emitting sphere —
-// the reference's own arithmetic with nothing nearer yet (limit = infinity).
-__device__ __forceinline__ bool camera_path_is_dead(const SceneDev &sc, const FrameDev &fr, Rng rng, float dx, float dy, float dz) {
-    const double a = rng_u01(rng), b = rng_u01(rng), c = rng_u01(rng);
-    const float r2m = (float)((double)fr.r2scale * c);
-    const bool ends_mat = !(a >= 0.96) && (1.0f - r2m) < 0.0f;
-    const bool ends_nomat = (1.0 - (double)fr.r2scale * b) < 0.0;
-    bool dead = ends_mat && ends_nomat;
-    for (uint32_t i = 0; i < sc.nspheres; ++i) {
-        const SphereDev &q = sc.spheres[i];
-        if ((q.flags & 1u) && __builtin_amdgcn_ballot_w64(dead) != 0) {
-            const float th = sphere_hit(fr.px, fr.py, fr.pz, dx, dy, dz, make_float4(q.cx, q.cy, q.cz, q.rad2), kInf);
-            if (th > 0.f) dead = false;
-        }
-    }
-    return dead;
-}
-
 // LIVE 0: every camera ray of the pass, rayA[pid].   LIVE 1 (VMX_SAMPLING_ELIDE_DEAD): nothing is written but one word
 // of live bits and its popcount per 64 consecutive path ids; launch_live_compact turns those into the ordered list of
 // live path ids and k_raygen_live writes their rays, densely, to rayA[position in that list].
@@ -1394,7 +1421,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
                     Rng rng;
                     primary_ray(fr, global_pixel(fr, lp), k, rng, dx, dy, dz);
                     depth = 0;
-                    if (LIVE) live = !camera_path_is_dead(sc, fr, rng, dx, dy, dz);
+                    if (LIVE) live = !step_is_dead<false, false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
                 }
                 if (!LIVE) ((float4 *)pa.rayA)[pid0 + lane] = make_float4(dx, dy, dz, __uint_as_float(depth));
             }
@@ -1418,7 +1445,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
             depth = 0;
-            if (LIVE) live = !camera_path_is_dead(sc, fr, rng, dx, dy, dz);
+            if (LIVE) live = !step_is_dead<false, false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
         }
         // camera rays share the origin (FrameDev): one 16-byte record (direction, depth flag) in rayA
         if (!LIVE && s_idx < wk.n_active) ((float4 *)pa.rayA)[pid] = make_float4(dx, dy, dz, __uint_as_float(depth));
@@ -2438,6 +2465,9 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             shade_trig(mid, fr.libm_double, cs, sn);
             alive = path_shade_end(P, c, fl, mid, cs, sn);
         }
+        if (fr.elide_dead && alive &&
+            step_is_dead<TEX, true>(sc, fr.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb, s_geom))
+            alive = false, fl.continues = false;  // VMX_SAMPLING_ELIDE_DEAD: the next ray cannot change the path's colour
         if (alive) {
             ray_store(pa, pid, P);
             rng_store(pa, pid, P.rng);
