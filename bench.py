@@ -125,8 +125,8 @@ def main():
     local = torch.empty((rows, W, 5), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step(early_stop=False, counters=False):
-        opts = va.make_opts(seed=args.seed, early_stop=early_stop, sampling=va.VMX_SAMPLING_PARITY, rank=rank,
+    def step(early_stop=False, counters=False, sampling=va.VMX_SAMPLING_PARITY):
+        opts = va.make_opts(seed=args.seed, early_stop=early_stop, sampling=sampling, rank=rank,
                             world=world, stripe_rows=stripe, collect_counters=counters, reorder=args.reorder)
         st = sc.render_device(cam, opts, local.data_ptr(), stream)
         st["kernels"] = sc.timings()  # per-kernel hipEvent durations of this frame (on the render stream)
@@ -174,6 +174,37 @@ def main():
         step(early_stop=True)
         es_k = max(1, min(args.steps, 3))
         es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
+
+    # VMX_SAMPLING_ELIDE_DEAD: the same frames, bit for bit, without the rays whose step cannot change the path's colour
+    # (78 % of them under the reference's r2 = 10 U).  Wall-clock per frame is the second half of BASELINE.json's metric;
+    # the headline value above stays the default build's, which traces every ray the reference traces.
+    el_info = None
+    if not args.no_extras:
+        ELIDE = va.VMX_SAMPLING_PARITY | va.VMX_SAMPLING_ELIDE_DEAD
+        same = []
+        for es in (False, True):
+            _, f0 = step(early_stop=es)
+            f0 = f0.clone() if f0 is not None else None  # (one GPU: the frame is the render target itself)
+            _, f1 = step(early_stop=es, sampling=ELIDE)
+            if rank == 0:
+                same.append(bool(torch.equal(f0.view(torch.int32), f1.view(torch.int32))))
+        el_k = max(1, min(args.steps, 3))
+        el_dt, el_rays, el_stats = timed(el_k, sampling=ELIDE)
+        ele_dt, ele_rays, ele_stats = timed(el_k, early_stop=True, sampling=ELIDE)
+
+        def kms(sts):
+            return {k: round(sum(x["kernels"][k]["ms"] for x in sts) / len(sts), 3)
+                    for k in sts[0]["kernels"] if sts[0]["kernels"][k]["launches"]}
+        el_info = {
+            "what": "the same two frames with VMX_SAMPLING_ELIDE_DEAD (opt-in): rays whose Radiance step provably cannot change "
+                    "the path's colour are not traced (vmx_kernels.hip: step_is_dead); rays_per_frame counts traced rays only",
+            "frames_bit_identical_to_default": all(same) if rank == 0 else None,
+            "fixed_count": {"ms_per_frame": round(el_dt / el_k * 1e3, 3), "rays_per_frame": int(el_rays / el_k),
+                            "speedup_vs_default": round(ms_per_step / (el_dt / el_k * 1e3), 2), "kernel_ms": kms(el_stats)},
+            "early_stop": {"ms_per_frame": round(ele_dt / el_k * 1e3, 3), "rays_per_frame": int(ele_rays / el_k),
+                           "speedup_vs_default": round((es_dt / es_k) / (ele_dt / el_k), 2) if es_k else None,
+                           "kernel_ms": kms(ele_stats)},
+        }
 
     # `corrected` sampling (r2 = U: a real cosine-weighted lobe, pathtracer.cpp:156,170 with the factor 10 removed):
     # SURVEY 8(d) / BASELINE.md §3 ask for it beside `parity`.  Bounces dominate here (~25 rays per sample).
@@ -413,6 +444,8 @@ def main():
         if q_info:
             out["quality_bvh"] = q_info
             out["quality_bvh_gpu_built"] = p_info
+        if el_info:
+            out["elided_frame"] = el_info
         if corr_info:
             out["corrected_frame"] = corr_info
         if bf_info:

@@ -584,6 +584,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     const uint32_t W = fr.width, rows = fr.local_rows;
     const uint32_t npix = W * rows;
     const bool count = opts->collect_counters != 0;
+    if (count) fr.elide_dead = 0;  // the counting build traces every ray: its totals are the oracle's
     // pipeline forms (all produce the same frame, bit for bit):
     //   0 split wavefront: k_trace_q + k_shade + id compaction (default)
     //   1 k_paths: refilling lanes keep their path to its end (no queues)
@@ -694,7 +695,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     if (ws.heads.ensure(kSubQueues * 32)) return fail(VMX_ERR_NOMEM, "work heads");
     if (ws.rad_mask.ensure(((size_t)n_pad_max * smax + 63) / 64 + 8)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the radiance mask");
     if (split_any) pa.rad_mask = ws.rad_mask.p;
-    const bool elide = split_any && fr.elide_dead && !count;  // (the counting build traces every path: its totals are the oracle's)
+    const bool elide = split_any && fr.elide_dead;  // camera paths of the split passes: compacted live list
     const size_t live_words_max = ((size_t)n_pad_max * smax + 63) / 64;
     size_t live_tmp_bytes = 0;
     if (elide) {

@@ -1526,11 +1526,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= refill_min || idle == ~0ull)) {
             for (;;) {
                 if (res_lo == res_hi) {
-                    uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
-                    if (SRC == 0 && wk.live_ids) {  // (scalar loads, once per reservation)
-                        const uint32_t n = *wk.live_count, seg = live_band(n);
-                        lim = min(seg, n - min(n, src * seg));
-                    }
+                    const uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&wk.heads[src * 32], kReserve);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -1566,8 +1562,6 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                         }
                         valid = s_idx < wk.n_active;
                         pid = path_id(wk, j, s_idx);
-                        // VMX_SAMPLING_ELIDE_DEAD: the live camera paths, dense in list order (ray and hit record at the list position)
-                        if (wk.live_ids) valid = true, pid = src * live_band(*wk.live_count) + item;
                     } else {
                         pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
                     }
@@ -1991,7 +1985,9 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
 #define VMX_PROF_STEP(EX, OC) step(EX, OC)
 #endif
 
-template <int SRC>
+// LIVE (SRC 0, VMX_SAMPLING_ELIDE_DEAD): the work is the dense list of live camera paths — ray and hit record of list
+// entry i sit at rayA[i] / hit[i] — cut into 8 bands of whole waves (live_band)
+template <int SRC, bool LIVE = false>
 __global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(VMX_TRACE_SGPRS)))
 k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     extern __shared__ uint2 lds_stack[];
@@ -2233,7 +2229,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             for (;;) {
                 if (res_lo == res_hi) {
                     uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
-                    if (SRC == 0 && wk.live_ids) {  // (scalar loads, once per reservation)
+                    if (LIVE) {  // (scalar loads, once per reservation)
                         const uint32_t n = *wk.live_count, seg = live_band(n);
                         lim = min(seg, n - min(n, src * seg));
                     }
@@ -2261,7 +2257,9 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                 res_lo = __builtin_amdgcn_readfirstlane(res_lo + min((uint32_t)__popcll(want), avail));
                 if (take) {
                     bool valid = true;
-                    if (SRC == 0) {
+                    if (LIVE) {
+                        pid = src * live_band(*wk.live_count) + item;  // list position
+                    } else if (SRC == 0) {
                         uint32_t j, s_idx;
                         if (wk.pixel_major) {
                             const uint32_t sl = item / wk.samples;
@@ -2271,8 +2269,6 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                         }
                         valid = s_idx < wk.n_active;
                         pid = path_id(wk, j, s_idx);
-                        // VMX_SAMPLING_ELIDE_DEAD: the live camera paths, dense in list order (ray and hit record at the list position)
-                        if (wk.live_ids) valid = true, pid = src * live_band(*wk.live_count) + item;
                     } else {
                         pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
                     }
@@ -2389,7 +2385,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
 #define VMX_SHADE_WPS 7  // waves per SIMD k_shade is compiled for (<= 72 VGPRs): left to itself hipcc takes 100 (5 waves) since the
                         // cosf/sinf path came in; k_shade<0> 14.6 ms at 5-6 waves (the cap at 6 spills into the hot path), 13.1 at 7, 13.4 at 8
 #endif
-template <int SRC, bool TEX>
+template <int SRC, bool TEX, bool ELIDE = false>
 __global__ void __launch_bounds__(256, VMX_SHADE_WPS)
 k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, IdQueue qout, uint32_t max_chunks,
         DevCounters *ctr) {
@@ -2407,7 +2403,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
     Tally tl = {{0, 0}, {0, 0}, {0, 0}};
     uint32_t items = SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues;
     // VMX_SAMPLING_ELIDE_DEAD: the pass's live camera paths only; ray and hit record sit at the list position `src`
-    const bool listed = SRC == 0 && wk.live_ids != nullptr;
+    constexpr bool listed = SRC == 0 && ELIDE;
     uint32_t live_n = 0;
     if (listed) live_n = *wk.live_count, items = (live_n + blockDim.x - 1) / blockDim.x;
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
@@ -2465,7 +2461,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             shade_trig(mid, fr.libm_double, cs, sn);
             alive = path_shade_end(P, c, fl, mid, cs, sn);
         }
-        if (fr.elide_dead && alive &&
+        if (ELIDE && alive &&
             step_is_dead<TEX, true>(sc, fr.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb, s_geom))
             alive = false, fl.continues = false;  // VMX_SAMPLING_ELIDE_DEAD: the next ray cannot change the path's colour
         if (alive) {
@@ -3029,6 +3025,7 @@ int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pi
     // production form: k_trace_w; with counters: the first form k_trace_q (same tests per ray)
     if (!count) {
         if (from_queue) hipLaunchKernelGGL((k_trace_w<1>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
+        else if (wk.live_ids) hipLaunchKernelGGL((k_trace_w<0, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
         else hipLaunchKernelGGL((k_trace_w<0>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
     } else {
         if (from_queue) hipLaunchKernelGGL((k_trace_q<true, 1>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, pa, counters);
@@ -3058,14 +3055,16 @@ int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pixe
                                       : ((uint64_t)wk.samples * wk.n_pad + 255) / 256;
     uint32_t grid = (uint32_t)std::min<uint64_t>(items, 256u * 16u);
     if (grid == 0) grid = 1;
-#define VMX_GO(S, T) \
-    hipLaunchKernelGGL((k_shade<S, T>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters)
+#define VMX_GO(S, T, E) \
+    hipLaunchKernelGGL((k_shade<S, T, E>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters)
+    // camera paths are shaded from the live list exactly when render_impl built one (wk.live_ids)
+    const bool elide = from_queue ? fr.elide_dead != 0 : wk.live_ids != nullptr;
     if (sc.tex) {
-        if (from_queue) VMX_GO(1, true);
-        else VMX_GO(0, true);
+        if (from_queue) { if (elide) VMX_GO(1, true, true); else VMX_GO(1, true, false); }
+        else { if (elide) VMX_GO(0, true, true); else VMX_GO(0, true, false); }
     } else {
-        if (from_queue) VMX_GO(1, false);
-        else VMX_GO(0, false);
+        if (from_queue) { if (elide) VMX_GO(1, false, true); else VMX_GO(1, false, false); }
+        else { if (elide) VMX_GO(0, false, true); else VMX_GO(0, false, false); }
     }
 #undef VMX_GO
     return launch_status();
