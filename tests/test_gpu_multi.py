@@ -40,6 +40,11 @@ def test_multi_render_equals_single_device_frame_and_the_oracle(world, stripe):
             assert st["samples"] == rst["samples"] == ost["samples"]
             if st["samples_discarded"] == 0:
                 assert st["rays_primary"] + st["rays_secondary"] == rst["rays_primary"] + rst["rays_secondary"]
+            # VMX_SAMPLING_ELIDE_DEAD through the same sharding (split passes): same frame, fewer rays
+            eopts = va.make_opts(seed=4, early_stop=es, stripe_rows=stripe, sampling=va.VMX_SAMPLING_ELIDE_DEAD, pipeline=4)
+            eimg, est = multi.render(cam, eopts)
+            assert np.array_equal(bits(eimg), bits(oimg)) and est["samples"] == ost["samples"]
+            assert est["rays_primary"] + est["rays_secondary"] < 0.5 * (ost["rays_primary"] + ost["rays_secondary"])
         # BruteForceTracer through the same sharding
         bf, _ = multi.render_bruteforce(cam, va.make_opts(seed=4, stripe_rows=stripe))
         bref, _ = osc.render_bruteforce(cam, va.make_opts(seed=4))

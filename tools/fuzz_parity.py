@@ -2,7 +2,8 @@
 random triangle soups (the generators of tests/test_gpu_parity.py), random cameras inside and outside the geometry,
 64 ... 256 samples per pixel (camera-ray waves of one pixel: the assembly loop with its uniform pops and leaves), leaf
 sizes 1 ... 16, all four tree builders (device-built trees: the oracle traverses the exported tree), both samplings, several
-LDS stack depths.  Frames, sample counts and ray counts must be bit-identical.   python tools/fuzz_parity.py [cases] [seed]"""
+LDS stack depths, random sphere tables, and every case again under VMX_SAMPLING_ELIDE_DEAD.  Frames and sample counts must be
+bit-identical.   python tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -28,20 +29,35 @@ for case in range(cases):
     cpos = rng.uniform(-900, 900, 3) if rng.random() < 0.5 else rng.uniform(-1900, 1900, 3) * np.array([1, 0.25, 1]) + np.array([0, 500, 0])
     rot = rng.uniform(-180, 180, 3) * np.array([0.3, 1.0, 0.1])
     cam = va.make_camera(tuple(float(v) for v in cpos), tuple(float(v) for v in rot), W, H, spp, back_size=(3.6, 3.6 * H / W))
+    # a random sphere table in one case of three (weak and strong emitters, big and small, some around the camera)
+    spheres = None
+    if rng.random() < 0.34:
+        tab = []
+        for _ in range(int(rng.integers(1, 9))):
+            ctr = cpos + rng.normal(0, 1, 3) * float(rng.choice([50, 400, 2000]))
+            tab.append(dict(centre=tuple(float(v) for v in ctr), radius=float(rng.choice([20, 150, 900, 5000])),
+                            colour=tuple(float(v) for v in rng.uniform(0, 1, 3) * float(rng.choice([0.3, 1.0, 3.0]))),
+                            emit=bool(rng.random() < 0.6), normal_sign=float(rng.choice([1, -1]))))
+        spheres = va.spheres_array(tab)
     kw = [{"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1}, {"pipeline": 4, "lds_entries": int(rng.choice([1, 3, 6, 40]))}, {}][rng.integers(0, 4)]
     try:
-        with va.Scene(pos, nrm, uv, leaf_size=leaf, builder=builder) as g:
-            osc = O.OracleScene(pos, nrm, uv, leaf_size=leaf, tree=g.bvh() if builder else None)
-            opts = va.make_opts(seed=int(rng.integers(1, 1 << 30)), early_stop=es, sampling=sampling, **kw)
+        with va.Scene(pos, nrm, uv, spheres=spheres, leaf_size=leaf, builder=builder) as g:
+            osc = O.OracleScene(pos, nrm, uv, spheres=spheres, leaf_size=leaf, tree=g.bvh() if builder else None)
+            seed = int(rng.integers(1, 1 << 30))
+            opts = va.make_opts(seed=seed, early_stop=es, sampling=sampling, **kw)
             img, st = g.render(cam, opts)
             ref, rst = osc.render(cam, opts)
             same = np.array_equal(bits(img), bits(ref)) and st["samples"] == rst["samples"]
+            # VMX_SAMPLING_ELIDE_DEAD: the same frame from fewer rays
+            img2, st2 = g.render(cam, va.make_opts(seed=seed, early_stop=es, sampling=sampling | va.VMX_SAMPLING_ELIDE_DEAD, **kw))
+            same = same and np.array_equal(bits(img2), bits(ref)) and st2["samples"] == rst["samples"]
+            same = same and st2["rays_primary"] + st2["rays_secondary"] <= st["rays_primary"] + st["rays_secondary"]
             osc.close()
     except va.VmxError as e:  # e.g. LBVH deeper than the reference's 64-entry stack on many coincident centroids
         print(f"case {case}: {kind} n={n} leaf={leaf} builder={builder}: {e}")
         continue
     bad += not same
     print(f"case {case:3d}: {kind:10s} n={n:5d} leaf={leaf:2d} builder={builder} spp={spp:3d} sampling={sampling:#x} es={int(es)} {kw} -> "
-          f"{'ok' if same else 'MISMATCH'} ({st['rays_primary'] + st['rays_secondary']} rays)", flush=True)
+          f"{'ok' if same else 'MISMATCH'} ({st['rays_primary'] + st['rays_secondary']} rays, {st2['rays_primary'] + st2['rays_secondary']} with elision{', spheres' if spheres is not None else ''})", flush=True)
 print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
