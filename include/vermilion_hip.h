@@ -56,15 +56,18 @@ extern "C" {
  * (uniform in [0, 2 pi)); of 10^6 paths' radiance none differed (tests/test_oracle.py). */
 #define VMX_SAMPLING_LIBM_DOUBLE 0x100u
 /* Flag, OR-ed into vmx_opts.sampling; OFF by default.  Under the reference's sampling (r2 = 10 U, pathtracer.cpp:156,170)
- * nine in ten diffuse bounces produce a NaN direction and end the path, and a path that ends at
- * its first hit returns exactly (0,0,0) unless that hit — or a nearer-so-far test on the way (meshEngine.cpp:377-420) — is
- * a light sphere.  Whether a camera path ends there is decided by its own random draws alone (the specular test :98 and
- * r2 :156 / :170, for both values of the material flag), and whether a light sphere can colour it by the ray alone.
- * With this flag such paths are not traced at all: the frame is bit-identical (Camera::mImage holds r,g,b and the sample
- * count, camera.cpp:106-113 — the primary hit distance Radiance also returns, :44-47, is not part of it), but
- * vmx_stats.rays_primary counts only the rays that were traced, so throughput figures are not comparable with the
- * default.  Applies to the split-wavefront passes of vmx_render* (not to vmx_radiance, whose output includes that
- * distance).  With VMX_SAMPLING_CORRECTED almost no path ends at its first hit and the flag changes little. */
+ * nine in ten diffuse bounces produce a NaN direction and end the path.  A Radiance step adds
+ * accumRadiance * hitColour (pathtracer.cpp:43), and hitColour is non-zero only where the hit — or a nearer-so-far test on
+ * the way (meshEngine.cpp:377-420) — is a light sphere.  Whether a step is the path's last one whatever it hits is
+ * decided by the path's own random draws alone (Russian roulette :56, the specular test :98 and r2 :156 / :170, for both
+ * values of the material flag), and whether a light sphere can colour it by the ray alone.  With this flag a ray whose
+ * step is provably the last one and cannot meet a light sphere is not traced — camera rays and bounce rays alike, 78 % of
+ * all rays of a parity frame: the frame is bit-identical (Camera::mImage holds r,g,b and the sample count,
+ * camera.cpp:106-113 — the primary hit distance Radiance also returns, :44-47, is not part of it), but
+ * vmx_stats.rays_primary / rays_secondary count only the rays that were traced, so throughput figures are not comparable
+ * with the default.  Applies to vmx_render* (split-wavefront and fused passes; not to vmx_radiance, whose output includes
+ * that distance, nor to a call with collect_counters, whose totals are the reference's).  With VMX_SAMPLING_CORRECTED
+ * (r2 = U) only Russian roulette past depth 5 ever ends a path by its draws alone and the flag changes little. */
 #define VMX_SAMPLING_ELIDE_DEAD 0x200u
 
 /*

@@ -258,6 +258,52 @@ def test_first_generation_kernels_give_the_same_frames(sponza):
         sponza.render(cam, va.make_opts(seed=1, early_stop=False, reorder=0x35, tail_threshold=1))
 
 
+def test_two_phase_shading_equals_one_phase(sponza):
+    """Split passes shade in two phases by default (k_shade_ends finishes the steps that end by their draws alone,
+    k_shade takes the rest in dense waves); vmx_opts.reserved[0] bit 8 asks for the one-phase form, and a call with
+    collect_counters always uses it.  Frames, ray counts, triangle-hit counts and continuation counts must agree —
+    on the bench scene at 1080p, with bounce generations through both forms (tail_threshold=1: no fused tail), with a
+    texture, and with a sphere table whose lights come after other spheres (SceneDev::emit_prefix)."""
+    cam = sponza_cam(1920, 1080, 16)
+    for es in (False, True):
+        for kw in (dict(pipeline=4), dict(pipeline=4, tail_threshold=1)):
+            a, sa = sponza.render(cam, va.make_opts(seed=3, early_stop=es, **kw))
+            b, sb = sponza.render(cam, va.make_opts(seed=3, early_stop=es, **dict(kw, pipeline=4 | 0x100)))
+            c, sc_ = sponza.render(cam, va.make_opts(seed=3, early_stop=es, collect_counters=True, **kw))
+            assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c)), (es, kw)
+            for other in (sb, sc_):
+                for key in ("samples", "samples_discarded", "rays_primary", "rays_secondary"):
+                    assert sa[key] == other[key], (es, kw, key)
+                for stage in ("primary", "bounce"):
+                    assert sa[stage]["tri_hits"] == other[stage]["tri_hits"], (es, kw, stage)
+    # lights late in the table, a weak one among them, a texture
+    pos, nrm, uv = scenes.bunny70k()
+    table = va.spheres_array([
+        dict(centre=(0, -5e7, 0), radius=5e7), dict(centre=(0, 5e7 + 1000, 0), radius=5e7),
+        dict(centre=(0, 700, 300), radius=220, colour=(1.5, 1.2, 0.9), emit=True),
+        dict(centre=(-5e7 + 2000, 0, 0), radius=5e7, normal_sign=-1),
+        dict(centre=(300, 400, 300), radius=90, colour=(0.3, 0.2, 0.1), emit=True),
+        dict(centre=(5e7 - 2000, 0, 0), radius=5e7, normal_sign=-1),
+        dict(centre=(0, 0, -5e7 + 2000), radius=5e7, normal_sign=-1), dict(centre=(0, 0, 5e7 - 2000), radius=5e7)])
+    c = scenes.bunny_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 256, 192, 32, back_size=(3.6, 2.7))
+    tex = (np.random.RandomState(4).random_sample((16, 16, 3)) * 1.2).astype(np.float32)
+    with va.Scene(pos, nrm, uv, spheres=table) as g:
+        osc = O.OracleScene(pos, nrm, uv, spheres=table)
+        for textured in (False, True):
+            if textured:
+                g.bind_texture(tex)
+                osc.bind_texture(tex)
+            for sampling in (0, 1):
+                ref, rst = osc.render(cam, va.make_opts(seed=8, early_stop=False, sampling=sampling))
+                for pipe in (4, 4 | 0x100):
+                    for tail in (0, 1):
+                        img, st = g.render(cam, va.make_opts(seed=8, early_stop=False, sampling=sampling, pipeline=pipe, tail_threshold=tail))
+                        assert np.array_equal(bits(img), bits(ref)), (textured, sampling, pipe, tail)
+                        assert st["rays_secondary"] == rst["rays_secondary"] and st["rays_primary"] == rst["rays_primary"]
+        osc.close()
+
+
 def test_threads_render_and_introspect_concurrently():
     """The ABI is blocking and a scene serialises its own calls (vmx_scene::mu); different scenes may be driven from
     different host threads at the same time, and vmx_scene_describe / _timings / _bvh may be called while another

@@ -12,8 +12,9 @@ sc = va.Scene(pos, nrm, uv)
 out = torch.empty((H, W, 5), device="cuda")
 for es in (False, True):
     ref = None
-    for flag, tail in [(0, 0)] + [(va.VMX_SAMPLING_ELIDE_DEAD, int(t)) for t in os.environ.get("TAIL", "0").split(",")]:
-        o = va.make_opts(seed=1, early_stop=es, sampling=flag, tail_threshold=tail)
+    for flag, tail, pipe in [(f, int(t), int(p, 0)) for p in os.environ.get("PIPE", "0").split(",") for f in (0, va.VMX_SAMPLING_ELIDE_DEAD)
+                             for t in os.environ.get("TAIL", "0").split(",")]:
+        o = va.make_opts(seed=1, early_stop=es, sampling=flag, tail_threshold=tail, pipeline=pipe)
         sc.render_device(cam, o, out.data_ptr())
         st = sc.render_device(cam, o, out.data_ptr()); torch.cuda.synchronize()
         t = sc.timings()
@@ -21,4 +22,4 @@ for es in (False, True):
         if ref is None: ref = img.copy()
         same = bool(np.array_equal(ref, img))
         k = {n: round(v["ms"], 2) for n, v in t.items() if v["launches"]}
-        print(f"early_stop={es} sampling={flag:#x} tail={tail}: frame {st['ms_device']:.2f} ms  rays {st['rays_primary']}+{st['rays_secondary']}  {k}  identical={same}", flush=True)
+        print(f"early_stop={es} sampling={flag:#x} tail={tail} pipeline={pipe:#x}: frame {st['ms_device']:.2f} ms  rays {st['rays_primary']}+{st['rays_secondary']}  {k}  identical={same}", flush=True)

@@ -111,7 +111,7 @@ void HipPathTracer::Render(std::vector<Vermilion::Camera *> &cameraList, MeshEng
         std::memset(&o, 0, sizeof(o));
         o.seed = mSeed;
         o.early_stop = 1;                    // pathtracer.cpp:290-311
-        o.sampling = VMX_SAMPLING_PARITY;    // r2 = 10*U, pathtracer.cpp:156
+        o.sampling = mSampling;              // default: r2 = 10*U (pathtracer.cpp:156), rays without effect not traced
         std::vector<float> frame((size_t)cam->RenderTargetSize * 5);
         vmx_stats st;
         if (renderFrame(c, o, false, 0, frame.data(), &st) != VMX_OK) {

@@ -70,6 +70,14 @@ class HipPathTracer : public HipIntegratorBase {
     explicit HipPathTracer(uint64_t seed = 1, int device = 0) : HipIntegratorBase(seed, {device}) {}
     HipPathTracer(uint64_t seed, std::vector<int> devices) : HipIntegratorBase(seed, std::move(devices)) {}
     void Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) override;
+    // vmx_opts.sampling of the frames.  Default: the reference's sampling with VMX_SAMPLING_ELIDE_DEAD — all Render
+    // leaves behind is Camera::mImage (r, g, b, sample count), which that flag keeps bit for bit while the frame takes a
+    // third of the time; uRaysFired then counts the rays that were traced.  setSampling(VMX_SAMPLING_PARITY) traces
+    // every ray the reference traces.
+    void setSampling(uint32_t sampling) { mSampling = sampling; }
+
+   private:
+    uint32_t mSampling = VMX_SAMPLING_PARITY | VMX_SAMPLING_ELIDE_DEAD;
 };
 
 // Replaces Vermilion::BruteForceTracer (core/integrators/integrators.h:18-21,

@@ -117,7 +117,7 @@ struct Workspace {
     DevBuf<unsigned int> heads;         // kSubQueues * 32 reservation heads of k_paths
     DevBuf<unsigned char> overflow_stack;  // k_paths: stack levels beyond the LDS part
     DevBuf<unsigned char> rayA, state, hit, thr;  // split wavefront: per-path state
-    DevBuf<unsigned int> ids[2], id_counts;             // split wavefront: live path ids
+    DevBuf<unsigned int> ids[3], id_counts;             // split wavefront: live path ids ([2]: two-phase shading)
     DevBuf<unsigned int> sort_keys[2], ids_sorted;      // bounce reordering (path_sort.hip)
     DevBuf<unsigned char> sort_tmp;
     DevBuf<unsigned char> cam_inner;                    // per-frame camera-relative scene tables: 8 node copies, then the triangles
@@ -127,6 +127,11 @@ struct Workspace {
     DevBuf<unsigned long long> live_mask;
     DevBuf<unsigned int> live_u32, live_ids;
     DevBuf<unsigned char> live_tmp;
+    // two-phase shading (k_shade_ends -> k_shade): the same three for the positions left to k_shade; their list is ids[2]
+    DevBuf<unsigned long long> full_mask;
+    DevBuf<unsigned int> full_u32;
+    DevBuf<unsigned char> full_tmp;
+    size_t full_words = 0, full_tmp_bytes = 0;
     DevBuf<unsigned char> accum;        // float4 per local pixel
     DevBuf<unsigned int> count, cursor, active[2], next_count;
     DevBuf<DevCounters> counters;
@@ -137,11 +142,12 @@ struct Workspace {
     void release() {
         queue_planes[0].release(), queue_planes[1].release(), queue_counts.release(), rad.release(), rad_mask.release(), heads.release(), overflow_stack.release();
         rayA.release(), state.release(), hit.release(), thr.release();
-        ids[0].release(), ids[1].release(), id_counts.release(), cam_inner.release();
+        ids[0].release(), ids[1].release(), ids[2].release(), id_counts.release(), cam_inner.release();
         sort_keys[0].release(), sort_keys[1].release(), ids_sorted.release(), sort_tmp.release();
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
         live_mask.release(), live_u32.release(), live_ids.release(), live_tmp.release();
+        full_mask.release(), full_u32.release(), full_tmp.release();
     }
 };
 
@@ -340,6 +346,7 @@ struct Tuning {
     uint32_t refill_min, refill_primary, shade_min, leaf_min, tail_threshold;
     uint32_t lds_entries, lds_primary, lds_bounce;  // LDS stack levels: fused kernels, camera-ray trace, bounce trace
     uint32_t sort_mode;  // bounce reordering: obits | dbits << 4 | dir_major << 8 | chunk_log2 << 12 | shade_sorted << 20
+    bool two_phase;      // split passes of vmx_render: k_shade_ends + k_shade on what it queues (render_impl)
 };
 
 Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
@@ -353,6 +360,7 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.shade_min = o->reserved[4] ? o->reserved[4] : 16u;
     tn.leaf_min = 0xFFFFFFFFu;
     tn.sort_mode = o->reserved[5];
+    tn.two_phase = false;
     // LDS stack levels per lane (+1 scratch level), 512 B per level and wave.  Measured on the Sponza
     // stand-in: camera rays rarely go deep and gain from the 8th wave per SIMD that 8 levels leave
     // room for (52.6 -> 50.6 ms); the bounce kernel, once its record fetch is quad-cooperative, prefers
@@ -400,13 +408,13 @@ LaunchCfg paths_cfg(const vmx_scene *sc, uint32_t entries, uint64_t items, int b
 }
 
 // ---- split wavefront (pipeline 0): k_trace_q + k_shade + id queues ---------------------------
-int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[2]) {
+int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[3]) {
     Workspace &ws = sc->ws;
     const uint32_t sub_cap = (uint32_t)(nslots / kSubQueues + 1024);
     if (ws.rayA.ensure(nslots * 16) || ws.state.ensure(nslots * 64) || ws.hit.ensure(nslots * 8) ||
         ws.rad.ensure(nslots * 16) ||
         ws.ids[0].ensure((size_t)sub_cap * kSubQueues) || ws.ids[1].ensure((size_t)sub_cap * kSubQueues) ||
-        ws.id_counts.ensure(2 * kSubQueues * 32) || ws.heads.ensure(kSubQueues * 32) || ws.counters.ensure(1))
+        ws.ids[2].ensure((size_t)sub_cap * kSubQueues) || ws.id_counts.ensure(3 * kSubQueues * 32) || ws.heads.ensure(kSubQueues * 32) || ws.counters.ensure(1))
         return fail(VMX_ERR_NOMEM, "hipMalloc failed for the path arrays");
     pa.rayA = ws.rayA.p, pa.state = ws.state.p;
     pa.hit = ws.hit.p, pa.rad = ws.rad.p;
@@ -416,7 +424,7 @@ int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[2]) {
         if (ws.thr.ensure(nslots * 16)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the throughput plane");
         pa.thr = ws.thr.p;
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {  // [0], [1]: the generations' ping-pong; [2]: k_shade_ends -> k_shade
         q[i].ids = ws.ids[i].p;
         q[i].counts = ws.id_counts.p + (size_t)i * kSubQueues * 32;
         q[i].sub_capacity = sub_cap;
@@ -425,9 +433,29 @@ int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[2]) {
     return VMX_OK;
 }
 
+// two-phase shading of one generation: k_shade_ends finishes the steps that end by their draws alone and marks the other
+// positions, launch_live_compact lists them in order, k_shade takes the list (wk.flat_ids) in dense waves.
+// nwords: words of 64 positions k_shade_ends covers; clear_first: it does not write all of them (live-path list)
+int shade_two_phase(vmx_scene *sc, const FrameDev &fr, WorkDev wk, PixelStateDev px, PathArrays pa, IdQueue q[3], IdQueue qout,
+                    uint32_t max_chunks, size_t nwords, bool clear_first, DevCounters *ctr, bool from_queue, hipStream_t s) {
+    Workspace &ws = sc->ws;
+    if (nwords > ws.full_words) return fail(VMX_ERR_INVALID, "two-phase shading: more positions than the workspace was sized for");
+    unsigned int *cnt = ws.full_u32.p, *offs = cnt + ws.full_words, *len = offs + ws.full_words;
+    if (clear_first) {
+        HIP_TRY(hipMemsetAsync(cnt, 0, nwords * 4, s));
+        HIP_TRY(hipMemsetAsync(ws.full_mask.p, 0, nwords * 8, s));
+    }
+    LAUNCH_TRY(launch_shade_ends(sc->dev, fr, wk, pa, ws.full_mask.p, cnt, max_chunks, ctr, from_queue, s));
+    HIP_TRY((hipError_t)launch_live_compact(ws.full_mask.p, cnt, (uint32_t)nwords, offs, q[2].ids, len, ws.full_tmp.p,
+                                            ws.full_tmp_bytes, s));
+    wk.flat_ids = q[2].ids, wk.flat_count = len;
+    LAUNCH_TRY(launch_shade(sc->dev, fr, wk, px, pa, qout, max_chunks, ctr, from_queue, s));
+    return VMX_OK;
+}
+
 // bounce generations of the split wavefront: trace + shade per generation while many paths are
 // alive, then one launch that follows the remaining paths to their end
-int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int cur, DevCounters *ctr, bool count,
+int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[3], int cur, DevCounters *ctr, bool count,
             const Tuning &tn, hipStream_t s, std::vector<TimedLaunch> &timed, uint64_t &launches, int trace_blocks,
             int tail_blocks) {
     Workspace &ws = sc->ws;
@@ -503,7 +531,13 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[2], int 
         if (!ts.a || !ts.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(ts.a, s));
         wk.qids = q_shade;
-        LAUNCH_TRY(launch_shade(sc->dev, fr, wk, nopx, pa, q[cur ^ 1], (largest + 255) / 256, ctr, true, s));
+        const uint32_t max_chunks = (largest + 255) / 256;
+        if (tn.two_phase) {
+            rc = shade_two_phase(sc, fr, wk, nopx, pa, q, q[cur ^ 1], max_chunks, (size_t)max_chunks * kSubQueues * 4, false, ctr, true, s);
+            if (rc) return rc;
+        } else {
+            LAUNCH_TRY(launch_shade(sc->dev, fr, wk, nopx, pa, q[cur ^ 1], max_chunks, ctr, true, s));
+        }
         HIP_TRY(hipEventRecord(ts.b, s));
         timed.push_back(ts);
         launches += 4;
@@ -591,8 +625,8 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     //   2 first-generation k_primary/k_bounce wavefront   3 k_primary following every path to the end
     //   4 split wavefront for every pass (form 0 hands passes of fewer than 4 M paths to form 1's
     //     kernel, which needs no per-generation host round trip)
-    const uint32_t pipeline = opts->reserved[0];
-    if (pipeline > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    const uint32_t pipeline = opts->reserved[0] & 0xFFu;  // (bit 8: one-phase shading, see two_phase below)
+    if (pipeline > 4 || (opts->reserved[0] & ~0x1FFu)) return fail(VMX_ERR_INVALID, "unknown pipeline form");
 #ifdef VMX_AB_KERNELS
     if (sc->dev.tex && pipeline >= 2 && pipeline <= 3)
         return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
@@ -607,7 +641,11 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     // that FOLLOW the first one of an early-stop frame are different: many slots, few of them valid (pixels that stopped
     // a stratum take 3 of up to 1024) — they run fused up to 32 M slots (round 3: 13.6 -> 12.9 ms before the pass merge)
     constexpr uint64_t kHybridPaths = 4ull << 20, kHybridLeftover = 32ull << 20;
-    const Tuning tn = make_tuning(sc, opts);
+    Tuning tn = make_tuning(sc, opts);
+    // two-phase shading of the split passes (k_shade_ends, then k_shade on what it queues) unless reserved[0] bit 8 asks
+    // for the one-phase form; the counting build keeps the one-phase form (an A/B of the two inside every test that
+    // compares a counted with an uncounted call)
+    tn.two_phase = !count && !(opts->reserved[0] & 0x100u);
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
         return VMX_OK;
@@ -633,7 +671,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         const size_t per_path = 16 + 64 + 8 + 16 + 8 + (sc->dev.tex ? 16 : 0) + (tn.sort_mode ? 12 : 0) + (fr.elide_dead ? 5 : 0);
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const size_t held = ws.rayA.n + ws.state.n + ws.hit.n + ws.rad.n + ws.thr.n + (ws.ids[0].n + ws.ids[1].n) * 4 +
+        const size_t held = ws.rayA.n + ws.state.n + ws.hit.n + ws.rad.n + ws.thr.n + (ws.ids[0].n + ws.ids[1].n + ws.ids[2].n) * 4 +
                             (ws.sort_keys[0].n + ws.sort_keys[1].n + ws.ids_sorted.n) * 4;
         mem_budget = (uint64_t)((free_b + held) / 10 * 9);
         if (const char *e = std::getenv("VMX_MEM_BUDGET_MB")) {
@@ -672,7 +710,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     QueueDev q[2];
 #endif
     PathArrays pa{};
-    IdQueue qi[2];
+    IdQueue qi[3];
     int tb = 1, tbb = 1;  // blocks per CU of the trace kernel: camera rays, bounce rays
     if (split_any) {
         rc = ensure_paths(sc, (size_t)n_pad_max * smax, pa, qi);
@@ -697,6 +735,13 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     if (split_any) pa.rad_mask = ws.rad_mask.p;
     const bool elide = split_any && fr.elide_dead;  // camera paths of the split passes: compacted live list
     const size_t live_words_max = ((size_t)n_pad_max * smax + 63) / 64;
+    if (split_any && tn.two_phase) {
+        const size_t words = live_words_max + 2048;  // camera passes: one word per 64 path ids; bounce generations: per 64 queue slots
+        const size_t tmp = live_compact_tmp_bytes((uint32_t)words);
+        if (ws.full_mask.ensure(words + 8) || ws.full_u32.ensure(2 * words + 16) || ws.full_tmp.ensure(tmp + 256))
+            return fail(VMX_ERR_NOMEM, "hipMalloc failed for the two-phase shading lists");
+        ws.full_words = words, ws.full_tmp_bytes = tmp;
+    }
     size_t live_tmp_bytes = 0;
     if (elide) {
         live_tmp_bytes = live_compact_tmp_bytes((uint32_t)live_words_max);
@@ -841,7 +886,14 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             TimedLaunch ts{ws.events.get(), ws.events.get(), 2, VMX_K_SHADE_CAMERA};
             if (!ts.a || !ts.b) return fail(VMX_ERR_HIP, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(ts.a, s));
-            LAUNCH_TRY(launch_shade(sc->dev, fr, wk, px, pa, qi[0], 0, ws.counters.p, false, s));
+            // (under VMX_SAMPLING_ELIDE_DEAD the camera paths left are mostly those that go on: one phase — 0.56 against
+            // 0.77 ms on the early-stop bench frame, no difference on the fixed-count one)
+            if (tn.two_phase && !elide) {
+                rc = shade_two_phase(sc, fr, wk, px, pa, qi, qi[0], 0, (size_t)(((uint64_t)n_pad * S + 63) / 64), false, ws.counters.p, false, s);
+                if (rc) return rc;
+            } else {
+                LAUNCH_TRY(launch_shade(sc->dev, fr, wk, px, pa, qi[0], 0, ws.counters.p, false, s));
+            }
             HIP_TRY(hipEventRecord(ts.b, s));
             timed.push_back(ts);
             launches += 2;
@@ -965,6 +1017,9 @@ static int scene_upload(vmx_scene *sc) {
     if (sd.size()) HIP_TRY(hipMemcpy(sc->d_spheres.p, sd.data(), sd.size() * sizeof(SphereDev), hipMemcpyHostToDevice));
     sc->dev.spheres = sc->d_spheres.p;
     sc->dev.nspheres = (uint32_t)sd.size();
+    sc->dev.emit_prefix = 0;
+    for (size_t i = 0; i < sd.size(); ++i)
+        if (sd[i].flags & 1u) sc->dev.emit_prefix = (uint32_t)i + 1;
     sc->dev.ntris = sc->ntris;
     if (sc->device_built) {
         // records were written on the device (k_lbvh_emit_*): the scene takes the builder's buffers over
@@ -1261,7 +1316,7 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     fr.libm_double = (opts->sampling & VMX_SAMPLING_LIBM_DOUBLE) ? 1u : 0u;
     fr.elide_dead = 0;
     PathArrays pa{};
-    IdQueue qi[2];
+    IdQueue qi[3];
     int tb = 1, rb = 1;
     const uint32_t lds_paths = (kPathsBlock / 64) * (tn.lds_entries + 1) * 512;
 #ifdef VMX_AB_KERNELS

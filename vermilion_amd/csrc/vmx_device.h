@@ -76,7 +76,8 @@ struct SceneDev {
     uint32_t tri_off;  // byte offset of `tris` from `inner` (one allocation: unified record fetch of k_trace_w<1>)
     // boundTextures[1]: BruteForceTracer's albedo (integrators.cpp:141-147)
     const float *tex1;
-    uint32_t tex1_w, tex1_h, tex1_c, tex1_pad;
+    uint32_t tex1_w, tex1_h, tex1_c;
+    uint32_t emit_prefix;  // index of the last VMX_SPHERE_EMIT sphere + 1 (0: none): hitColour is decided by spheres [0, emit_prefix)
 };
 
 // per-stage device counters (one set for depth-0 steps, one for bounce steps)

@@ -74,6 +74,9 @@ struct WorkDev {
     unsigned int *live_cnt;
     const unsigned int *live_ids;
     const unsigned int *live_count;  // device scalar: entries of live_ids
+    // two-phase shading: the ordered list of positions k_shade_ends left for k_shade (NULL: one phase)
+    const unsigned int *flat_ids;
+    const unsigned int *flat_count;
     // camera rays: per-frame origin-relative node / triangle tables (k_camera_tables)
     const void *cam_inner;  // float4[8 * n_inner * 4]: one copy per direction octant, octant 0 = plain (lo, hi)
     uint32_t cam_n_inner;   // records per copy
@@ -133,6 +136,8 @@ int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, 
 // ... and the wide shading kernel: RayCast tail + Radiance step + id compaction
 int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                  IdQueue qout, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream);
+int launch_shade_ends(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathArrays pa, unsigned long long *full_mask,
+                      unsigned int *full_cnt, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream);
 // follows every queued path (ids) to its end in one launch
 int launch_tail(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathArrays pa, DevCounters *counters,
                 bool count, LaunchCfg cfg, void *stream);

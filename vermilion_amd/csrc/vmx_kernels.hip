@@ -749,6 +749,17 @@ __device__ __forceinline__ bool step_is_dead(const SceneDev &sc, float r2scale, 
     return dead;
 }
 
+// The draws that decide whether a Radiance step is the path's last one whatever it hits (see step_is_dead), for the camera
+// step (depth 0: no Russian roulette): bit 0 = it ends if the hit has a material, bit 1 = it ends if it has none.
+// k_raygen leaves them in the ray record's fourth word; k_shade_ends reads them instead of re-keying the stream.
+__device__ __forceinline__ uint32_t camera_step_ends(float r2scale, Rng rng) {
+    const double a = rng_u01(rng), b = rng_u01(rng), c = rng_u01(rng);
+    const float r2m = (float)((double)r2scale * c);
+    const bool ends_mat = !(a >= 0.96) && (1.0f - r2m) < 0.0f;
+    const bool ends_nomat = (1.0 - (double)r2scale * b) < 0.0;
+    return (ends_mat ? 1u : 0u) | (ends_nomat ? 2u : 0u);
+}
+
 // Radiance's loop body after RayCast in one piece (the fused kernels)
 template <bool TEX, bool LDS_GEOM = false>
 __device__ __forceinline__ bool path_shade(const SceneDev &sc, SampCfg cfg, Path &P, const CastResult &c,
@@ -1393,8 +1404,9 @@ __global__ void k_camera_tables(SceneDev sc, uint32_t n_inner, float ox, float o
 
 // ---------------------------------------------------------------------------
 // k_raygen — camera rays of one pass (pathtracer.cpp:251-280), written to rayA[pid] as
-// (direction, depth flag): all camera rays share the frame's origin, so 16 bytes per ray suffice.
-// Slots whose sample index is past the pixel's last sample get depth = ~0 and are skipped downstream.
+// (direction, flag word): all camera rays share the frame's origin, so 16 bytes per ray suffice.
+// Slots without a sample (past the pixel's last one, padding) get the word ~0 and are skipped downstream;
+// the others the two camera_step_ends bits of their first Radiance step.
 // ---------------------------------------------------------------------------
 // LIVE 0: every camera ray of the pass, rayA[pid].   LIVE 1 (VMX_SAMPLING_ELIDE_DEAD): nothing is written but one word
 // of live bits and its popcount per 64 consecutive path ids; launch_live_compact turns those into the ordered list of
@@ -1420,10 +1432,12 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
                 if (k < fr.kmax) {
                     Rng rng;
                     primary_ray(fr, global_pixel(fr, lp), k, rng, dx, dy, dz);
-                    depth = 0;
                     if (LIVE) live = !step_is_dead<false, false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+                    else depth = camera_step_ends(fr.r2scale, rng);
                 }
                 if (!LIVE) ((float4 *)pa.rayA)[pid0 + lane] = make_float4(dx, dy, dz, __uint_as_float(depth));
+            } else if (!LIVE) {  // padding slots of the pass: marked like sample slots past a pixel's last sample
+                ((float4 *)pa.rayA)[pid0 + lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
             }
             if (LIVE) {
                 const unsigned long long bits = __builtin_amdgcn_ballot_w64(live);
@@ -1444,11 +1458,12 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
         if (s_idx < wk.n_active && primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
-            depth = 0;
             if (LIVE) live = !step_is_dead<false, false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+            else depth = camera_step_ends(fr.r2scale, rng);
         }
-        // camera rays share the origin (FrameDev): one 16-byte record (direction, depth flag) in rayA
-        if (!LIVE && s_idx < wk.n_active) ((float4 *)pa.rayA)[pid] = make_float4(dx, dy, dz, __uint_as_float(depth));
+        // camera rays share the origin (FrameDev): one 16-byte record in rayA — direction, and a word that is ~0 for a
+        // slot without a sample (past the pixel's last one, or padding), else the step's camera_step_ends bits
+        if (!LIVE) ((float4 *)pa.rayA)[pid] = make_float4(dx, dy, dz, __uint_as_float(depth));
         if (LIVE) {
             const unsigned long long bits = __builtin_amdgcn_ballot_w64(live);
             if ((threadIdx.x & 63u) == 0) wk.live_mask[pid >> 6] = bits, wk.live_cnt[pid >> 6] = (uint32_t)__popcll(bits);
@@ -1471,7 +1486,7 @@ k_raygen_live(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
         if (primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {  // (always: the path was found live from the same item)
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
-            depth = 0;
+            depth = camera_step_ends(fr.r2scale, rng);
         }
         ((float4 *)pa.rayA)[i] = make_float4(dx, dy, dz, __uint_as_float(depth));
     }
@@ -1567,10 +1582,10 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                     }
                     if (valid) {
                         uint32_t depth;
-                        if (SRC == 0) {  // camera ray: (direction, depth flag), origin from the frame
+                        if (SRC == 0) {  // camera ray: (direction, flag word), origin from the frame
                             const float4 a = ((const float4 *)pa.rayA)[pid];
                             ox = fr.px, oy = fr.py, oz = fr.pz, dx = a.x, dy = a.y, dz = a.z;
-                            depth = __float_as_uint(a.w);
+                            depth = __float_as_uint(a.w) == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u;  // (else: camera_step_ends bits)
                         } else {
                             const float4 a = ((const float4 *)pa.state)[(size_t)pid * 4], b = ((const float4 *)pa.state)[(size_t)pid * 4 + 1];
                             ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
@@ -2273,7 +2288,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                         pid = wk.qids.ids[(size_t)src * wk.qids.sub_capacity + item];
                     }
                     if (valid) {
-                        if (SRC == 0) {  // camera ray: (direction, depth flag), origin from the frame
+                        if (SRC == 0) {  // camera ray: (direction, flag word), origin from the frame
                             const float4 a = ((const float4 *)pa.rayA)[pid];
                             ox = fr.px, oy = fr.py, oz = fr.pz, dx = a.x, dy = a.y, dz = a.z;
                             valid = __float_as_uint(a.w) != 0xFFFFFFFFu;  // sample slot past the pixel's last sample
@@ -2385,7 +2400,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
 #define VMX_SHADE_WPS 7  // waves per SIMD k_shade is compiled for (<= 72 VGPRs): left to itself hipcc takes 100 (5 waves) since the
                         // cosf/sinf path came in; k_shade<0> 14.6 ms at 5-6 waves (the cap at 6 spills into the hot path), 13.1 at 7, 13.4 at 8
 #endif
-template <int SRC, bool TEX, bool ELIDE = false>
+template <int SRC, bool TEX, bool ELIDE = false, bool FROMQ = false>
 __global__ void __launch_bounds__(256, VMX_SHADE_WPS)
 k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, IdQueue qout, uint32_t max_chunks,
         DevCounters *ctr) {
@@ -2401,17 +2416,29 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
     }
     __syncthreads();
     Tally tl = {{0, 0}, {0, 0}, {0, 0}};
-    uint32_t items = SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues;
+    // FROMQ (two-phase shading): the work is the ordered list k_shade_ends + launch_live_compact left — the positions
+    // of the paths whose step does not end by its draws alone (wk.flat_ids, *wk.flat_count).  A position is an index
+    // into rayA / hit for camera paths (`src`), a place in the id queue for bounce paths
+    uint32_t items = (SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues);
+    uint32_t flat_n = 0;
+    if (FROMQ) flat_n = *wk.flat_count, items = (flat_n + blockDim.x - 1) / blockDim.x;
     // VMX_SAMPLING_ELIDE_DEAD: the pass's live camera paths only; ray and hit record sit at the list position `src`
     constexpr bool listed = SRC == 0 && ELIDE;
     uint32_t live_n = 0;
-    if (listed) live_n = *wk.live_count, items = (live_n + blockDim.x - 1) / blockDim.x;
+    if (listed) {
+        live_n = *wk.live_count;
+        if (!FROMQ) items = (live_n + blockDim.x - 1) / blockDim.x;
+    }
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
         bool run;
         uint32_t pid = 0, src = 0;
         Path P;
         if (SRC == 0) {
             src = pid = item * blockDim.x + threadIdx.x;
+            if (FROMQ) {
+                src = pid = src < flat_n ? wk.flat_ids[src] : 0xFFFFFFFFu;
+                if (listed) live_n = 0xFFFFFFFFu;  // (a listed position is a valid one)
+            }
             if (listed) pid = src < live_n ? wk.live_ids[src] : 0xFFFFFFFFu;  // (no such path: j >= samples below)
             uint32_t j, s_idx;
             if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
@@ -2430,9 +2457,16 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
                 P.tr = P.tg = P.tb = 1.f;  // :30
             }
         } else {
-            const uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
-            const uint32_t pos = chunk * blockDim.x + threadIdx.x;
-            run = pos < min(wk.qids.counts[sub * 32], wk.qids.sub_capacity);
+            uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
+            uint32_t pos = chunk * blockDim.x + threadIdx.x;
+            if (FROMQ) {  // a listed position = (block item of k_shade_ends) * 256 + lane
+                const uint32_t at = item * blockDim.x + threadIdx.x;
+                run = at < flat_n;
+                const uint32_t p = run ? wk.flat_ids[at] : 0u;
+                sub = (p >> 8) % kSubQueues, chunk = (p >> 8) / kSubQueues, pos = chunk * 256u + (p & 255u);
+            } else {
+                run = pos < min(wk.qids.counts[sub * 32], wk.qids.sub_capacity);
+            }
             if (run) {
                 pid = wk.qids.ids[(size_t)sub * wk.qids.sub_capacity + pos];
                 path_load_arrays<TEX>(pa, pid, P);
@@ -2475,7 +2509,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             // aligned word of the mask (path ids of an item are consecutive, 256 per block)
             const bool need = run && (alive || P.ar != 0.f || P.ag != 0.f || P.ab != 0.f);
             if (need) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
-            if (listed) {  // the mask was cleared for the pass; the list's neighbours share words
+            if (listed || FROMQ) {  // the mask was cleared for the pass / written by k_shade_ends; neighbours share words
                 if (need) atomicOr(&pa.rad_mask[pid >> 6], 1ull << (pid & 63u));
             } else {
                 const unsigned long long word = __builtin_amdgcn_ballot_w64(need);
@@ -2484,6 +2518,151 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
         }
         tally_add(tl, fl, run, depth0);
         id_append(qout, item % kSubQueues, alive, pid);
+    }
+    const Cnt none = {0, 0};
+    tally_flush<false>(ctr, tl, none, none);
+}
+
+// ---------------------------------------------------------------------------
+// k_shade_ends — first phase of the two-phase shading of a frame's split passes.  Under the reference's sampling four
+// Radiance steps in five are the path's last one because of the path's own draws (Russian roulette :56; r2 = 10 U > 1,
+// :156 / :170, where the hit's material flag — "the BVH hit a triangle", meshEngine.cpp:370 — picks the draw).  All
+// such a step does is accumColour += accumRadiance * hitColour (:43): neither the hit's normal, nor its uv, nor the
+// nearest distance is ever read.  And hitColour is decided by the sphere table's entries up to the last light
+// (SceneDev::emit_prefix; `testHit < nearestHit` in table order, meshEngine.cpp:377-420).  This kernel takes every
+// path of the generation, finishes those steps with exactly that — no attribute gather, no interpolation, 2 sphere
+// tests instead of 8 with the reference's table — and marks the others (one bit per position; launch_live_compact
+// makes the ordered list of them) for k_shade, which then runs in dense waves.  Same colours, same counters.
+// (k_shade alone does the same work with four lanes in five idle behind the branch: 13.1 ms against 3.9 + 4 here
+// for the 530.8 M camera paths of the bench frame.)
+//   SRC 0: camera paths; the two "ends" bits come with the ray record (k_raygen: camera_step_ends)
+//   SRC 1: queued bounce paths; the draws are read off a copy of the path's stream
+//   LISTED (SRC 0, VMX_SAMPLING_ELIDE_DEAD): the pass's live-path list instead of all its path ids
+// ---------------------------------------------------------------------------
+template <int SRC, bool TEX, bool LISTED>
+__global__ void __launch_bounds__(256)
+k_shade_ends(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa, unsigned long long *__restrict__ full_mask,
+             unsigned int *__restrict__ full_cnt, uint32_t max_chunks, DevCounters *ctr) {
+    const float2 *__restrict__ hits = (const float2 *)pa.hit;
+    float4 *__restrict__ rad = (float4 *)pa.rad;
+    __shared__ float4 s_geom[kLdsSpheres];
+    __shared__ float4 s_cam_op[kLdsSpheres];
+    __shared__ float4 s_col[kLdsSpheres];  // (colour, emits)
+    const uint32_t nlight = min(sc.emit_prefix, kLdsSpheres);
+    if (threadIdx.x < nlight) {
+        const SphereDev &q = sc.spheres[threadIdx.x];
+        s_geom[threadIdx.x] = make_float4(q.cx, q.cy, q.cz, q.rad2);
+        const float opx = q.cx - fr.px, opy = q.cy - fr.py, opz = q.cz - fr.pz;
+        s_cam_op[threadIdx.x] = make_float4(opx, opy, opz, dot3(opx, opy, opz, opx, opy, opz));
+        s_col[threadIdx.x] = make_float4(q.colr, q.colg, q.colb, (q.flags & 1u) ? 1.f : 0.f);
+    }
+    __syncthreads();
+    Tally tl = {{0, 0}, {0, 0}, {0, 0}};
+    uint32_t items = SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues;
+    uint32_t live_n = 0;
+    if (LISTED) live_n = *wk.live_count, items = (live_n + blockDim.x - 1) / blockDim.x;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        bool run, ends = false, material = false;
+        uint32_t pid = 0, src = 0, depth = 0;
+        float ox = fr.px, oy = fr.py, oz = fr.pz, dx = 0.f, dy = 0.f, dz = 0.f, best = 0.f;
+        float tr = 1.f, tg = 1.f, tb = 1.f;
+        if (SRC == 0) {
+            src = pid = item * blockDim.x + threadIdx.x;
+            run = LISTED ? src < live_n : src < wk.samples * wk.n_pad;
+            if (run) {
+                if (LISTED) pid = wk.live_ids[src];
+                const float4 a = ((const float4 *)pa.rayA)[src];
+                const uint32_t bits = __float_as_uint(a.w);
+                run = bits != 0xFFFFFFFFu;  // a slot without a sample
+                const float2 h = hits[src];
+                dx = a.x, dy = a.y, dz = a.z, best = h.x;
+                material = __float_as_int(h.y) >= 0;
+                ends = ((material ? bits : bits >> 1) & 1u) != 0;
+            }
+        } else {
+            const uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
+            const uint32_t pos = chunk * blockDim.x + threadIdx.x;
+            run = pos < min(wk.qids.counts[sub * 32], wk.qids.sub_capacity);
+            if (run) {
+                src = pid = wk.qids.ids[(size_t)sub * wk.qids.sub_capacity + pos];
+                Path P;
+                ray_load(pa, pid, P);
+                Rng r;
+                rng_load(pa, pid, r);
+                ox = P.ox, oy = P.oy, oz = P.oz, dx = P.dx, dy = P.dy, dz = P.dz, depth = P.depth;
+                const float2 h = hits[pid];
+                best = h.x;
+                material = __float_as_int(h.y) >= 0;
+                // the draws of this step, in path_shade_begin's order
+                bool rr_end = false;
+                if (depth + 1u > 5u) {
+                    const double rr = rng_u01(r);
+                    rr_end = rr > (double)0.95f || depth + 1u > 1000u;
+                }
+                if (material) {
+                    const double a = rng_u01(r);
+                    (void)rng_next(r);
+                    const double c = rng_u01(r);
+                    ends = !(a >= 0.96) && (1.0f - (float)((double)fr.r2scale * c)) < 0.0f;
+                } else {
+                    (void)rng_next(r);
+                    const double b = rng_u01(r);
+                    ends = (1.0 - (double)fr.r2scale * b) < 0.0;
+                }
+                ends = ends || rr_end;
+                if (TEX) {
+                    const float4 th = ((const float4 *)pa.thr)[pid];
+                    tr = th.x, tg = th.y, tb = th.z;
+                    if (!finite3(tr, tg, tb)) ends = false;  // inf * 0: leave the step to k_shade
+                }
+            }
+        }
+        const bool fin = run && ends;
+        // hitColour of the ending steps: the sphere table up to its last light, `testHit > 0 && testHit < nearestHit` in order
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+        if (__builtin_amdgcn_ballot_w64(fin) != 0) {
+            float nearest = material ? best : kInf;
+            for (uint32_t i = 0; i < nlight; ++i) {
+                float th;
+                if (SRC == 0) {
+                    const float4 q = s_cam_op[i];
+                    th = sphere_hit_op(q.x, q.y, q.z, q.w, s_geom[i].w, dx, dy, dz, nearest);
+                } else {
+                    th = sphere_hit(ox, oy, oz, dx, dy, dz, s_geom[i], nearest);
+                }
+                if (fin && th > 0.f && th < nearest) {
+                    nearest = th;
+                    const float4 col = s_col[i];
+                    if (col.w != 0.f) cr = col.x, cg = col.y, cb = col.z;
+                }
+            }
+        }
+        const bool lit = fin && (cr != 0.f || cg != 0.f || cb != 0.f);
+        if (SRC == 0) {
+            // accumColour = 0 + 1 * hitColour; stored only where it is not zero (PathArrays::rad_mask)
+            if (lit) rad[pid] = make_float4(0.f + tr * cr, 0.f + tg * cg, 0.f + tb * cb, -100.f);
+            if (LISTED) {  // the mask was cleared for the pass
+                if (lit) atomicOr(&pa.rad_mask[pid >> 6], 1ull << (pid & 63u));
+            } else {       // this wave's 64 path ids are one word; k_shade ORs the bits of its paths in afterwards
+                const unsigned long long word = __builtin_amdgcn_ballot_w64(lit);
+                if ((threadIdx.x & 63u) == 0 && src < wk.samples * wk.n_pad) pa.rad_mask[src >> 6] = word;
+            }
+        } else if (lit) {
+            float4 acc = rad[pid];
+            if (TEX) acc.x = acc.x + tr * cr, acc.y = acc.y + tg * cg, acc.z = acc.z + tb * cb;
+            else acc.x = acc.x + cr, acc.y = acc.y + cg, acc.z = acc.z + cb;
+            rad[pid] = acc;
+        }
+        StepFlags fl = {false, false, false};
+        fl.was_ray = depth == 0u ? true : finite3(dx, dy, dz);
+        fl.tri_hit = material;
+        tally_add(tl, fl, fin, depth == 0u ? 1u : 0u);
+        // the others: one word of bits per wave (position = block item * 256 + lane), compacted in order afterwards
+        const unsigned long long full = __builtin_amdgcn_ballot_w64(run && !ends);
+        if ((threadIdx.x & 63u) == 0) {
+            const uint32_t w = item * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            full_mask[w] = full, full_cnt[w] = (uint32_t)__popcll(full);
+        }
     }
     const Cnt none = {0, 0};
     tally_flush<false>(ctr, tl, none, none);
@@ -3048,23 +3227,62 @@ int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, 
     return (int)e;
 }
 
+// from_queue: bounce paths (wk.qids), else the camera paths of the pass.  wk.flat_ids: the second phase after
+// launch_shade_ends + launch_live_compact — only the listed positions.
 int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                  IdQueue qout, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    const uint64_t items = from_queue ? (uint64_t)max_chunks * kSubQueues
-                                      : ((uint64_t)wk.samples * wk.n_pad + 255) / 256;
-    uint32_t grid = (uint32_t)std::min<uint64_t>(items, 256u * 16u);
+    const bool flat = wk.flat_ids != nullptr;  // second phase: the list's length is known on the device only -> a full grid
+    // 7 blocks per CU are resident (VMX_SHADE_WPS); more blocks only add end-of-block counter atomics, which a small pass
+    // feels (early-stop frame, first pass: 1.70 ms with 4096 blocks, 1.05 with 1792; the bench frame's 530.8 M paths: no change)
+    constexpr uint32_t kShadeGrid = 256u * VMX_SHADE_WPS;
+    const uint64_t items = flat ? kShadeGrid : (from_queue ? (uint64_t)max_chunks * kSubQueues : ((uint64_t)wk.samples * wk.n_pad + 255) / 256);
+    uint32_t grid = (uint32_t)std::min<uint64_t>(items, kShadeGrid);
     if (grid == 0) grid = 1;
-#define VMX_GO(S, T, E) \
-    hipLaunchKernelGGL((k_shade<S, T, E>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters)
+#define VMX_GO(S, T, E, Q) \
+    hipLaunchKernelGGL((k_shade<S, T, E, Q>), dim3(grid), dim3(256), 0, s, sc, fr, wk, px, pa, qout, max_chunks, counters)
+#define VMX_GO_T(S, E, Q)                \
+    do {                                 \
+        if (sc.tex) VMX_GO(S, true, E, Q); \
+        else VMX_GO(S, false, E, Q);     \
+    } while (0)
     // camera paths are shaded from the live list exactly when render_impl built one (wk.live_ids)
     const bool elide = from_queue ? fr.elide_dead != 0 : wk.live_ids != nullptr;
-    if (sc.tex) {
-        if (from_queue) { if (elide) VMX_GO(1, true, true); else VMX_GO(1, true, false); }
-        else { if (elide) VMX_GO(0, true, true); else VMX_GO(0, true, false); }
+    if (from_queue) {
+        if (flat) { if (elide) VMX_GO_T(1, true, true); else VMX_GO_T(1, false, true); }
+        else { if (elide) VMX_GO_T(1, true, false); else VMX_GO_T(1, false, false); }
+    } else if (flat) {
+        if (elide) VMX_GO_T(0, true, true);
+        else VMX_GO_T(0, false, true);
     } else {
-        if (from_queue) { if (elide) VMX_GO(1, false, true); else VMX_GO(1, false, false); }
-        else { if (elide) VMX_GO(0, false, true); else VMX_GO(0, false, false); }
+        if (elide) VMX_GO_T(0, true, false);
+        else VMX_GO_T(0, false, false);
+    }
+#undef VMX_GO_T
+#undef VMX_GO
+    return launch_status();
+}
+
+// first phase of the two-phase shading (k_shade_ends): finishes the steps that end by their draws alone, queues the
+// others' positions in full_mask / full_cnt (one word per wave of 64 positions) for launch_live_compact + launch_shade
+int launch_shade_ends(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PathArrays pa, unsigned long long *full_mask,
+                      unsigned int *full_cnt, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t items = from_queue ? (uint64_t)max_chunks * kSubQueues : ((uint64_t)wk.samples * wk.n_pad + 255) / 256;
+    constexpr uint32_t kEndsGrid = 256u * 8u;  // 8 waves per SIMD resident; see launch_shade
+    uint32_t grid = (uint32_t)std::min<uint64_t>(items, kEndsGrid);
+    if (grid == 0) grid = 1;
+#define VMX_GO(S, T, L) \
+    hipLaunchKernelGGL((k_shade_ends<S, T, L>), dim3(grid), dim3(256), 0, s, sc, fr, wk, pa, full_mask, full_cnt, max_chunks, counters)
+    if (from_queue) {
+        if (sc.tex) VMX_GO(1, true, false);
+        else VMX_GO(1, false, false);
+    } else if (wk.live_ids) {
+        if (sc.tex) VMX_GO(0, true, true);
+        else VMX_GO(0, false, true);
+    } else {
+        if (sc.tex) VMX_GO(0, true, false);
+        else VMX_GO(0, false, false);
     }
 #undef VMX_GO
     return launch_status();
