@@ -48,8 +48,8 @@ A_TRI = {"trace_camera": 36, "trace_bounce": 53}
 KERNEL_TEXT = {
     "trace_camera": "k_trace_w<0> (persistent BVH traversal of the camera rays)",
     "trace_bounce": "k_trace_w<1> (persistent BVH traversal of a bounce generation, quad-cooperative record fetch)",
-    "shade_camera": "k_shade<0> (RayCast tail + Radiance step of the camera rays)",
-    "shade_bounce": "k_shade<1>", "tail": "k_paths<2> (fused tail of the last bounce generations)",
+    "shade_camera": "k_shade_ends<0> + list compaction + k_shade<0> (RayCast tail + Radiance step of the camera rays, two phases)",
+    "shade_bounce": "k_shade_ends<1> + list compaction + k_shade<1>", "tail": "k_paths<2> (fused tail of the last bounce generations)",
     "raygen": "k_raygen", "resolve": "k_resolve", "fused": "k_paths<0>",
 }
 
