@@ -301,6 +301,19 @@ def main():
         if os.path.exists(ppath) and world == 1 and (W, H, spp, args.scene) == (1920, 1080, 256, "sponza260k"):
             try:
                 prof = json.load(open(ppath))["kernels"]
+                # one timed interval of the library (vmx_timings) covers both shading phases: add their counters up
+                # (instructions, cache accesses and HBM bytes are additive; lane utilisation weighted by instructions)
+                for stage in ("camera", "bounce"):
+                    a, b = prof.get("shade_ends_" + stage, {}).get("derived"), prof.get("shade_" + stage, {}).get("derived")
+                    if a and b:
+                        va_, vb_ = a.get("valu_wave_insts_per_launch", 0.0), b.get("valu_wave_insts_per_launch", 0.0)
+                        if va_ + vb_ > 0:
+                            b["valu_lane_utilization"] = (a.get("valu_lane_utilization", 0.0) * va_
+                                                          + b.get("valu_lane_utilization", 0.0) * vb_) / (va_ + vb_)
+                        for key in ("valu_wave_insts_per_launch", "salu_wave_insts_per_launch", "l1_accesses_per_launch",
+                                    "hbm_bytes_per_launch"):
+                            if key in a and key in b:
+                                b[key] = b[key] + a[key]
             except Exception:
                 prof = None
 
