@@ -492,9 +492,22 @@ struct MtRng {
     float jitter() { return df(eng); }
 };
 
+/* Audit of the argument behind the kernels' two-phase shading and VMX_SAMPLING_ELIDE_DEAD, made on the
+ * oracle's own Radiance: before every step, from a COPY of the stream, predict "this is the path's last step whatever
+ * it hits" per value of the material flag, and "no light sphere can colour it"; after the step, check what happened. */
+struct ElisionAudit {
+    uint64_t steps = 0;             /* Radiance steps audited */
+    uint64_t predicted_last = 0;    /* steps predicted to be the last one for the material flag the hit turned out to have */
+    uint64_t predicted_dead = 0;    /* steps predicted last for BOTH values, with no light sphere in reach: the ray is not needed */
+    uint64_t not_last = 0;          /* violations: predicted last, but the path went on with a direction that is not all NaN */
+    uint64_t dead_changed = 0;      /* violations: predicted dead, but accumColour.rgb changed */
+    uint64_t colour_mismatch = 0;   /* violations: predicted last, but accumColour is not before + accumRadiance * (hitColour
+                                       as decided by the sphere table up to its last light) */
+};
 struct PathStats {
     uint64_t rays_primary = 0, rays_secondary = 0, tri_hits = 0, continued = 0;
     Counters cnt;
+    ElisionAudit *audit = nullptr;
 };
 
 /* bit test, so that the -Ofast (finite-math-only) baseline build cannot fold it away */
@@ -577,6 +590,71 @@ inline float libm_sincosf(float y, int which) {
 inline float restated_sinf(float y) { return libm_sincosf(y, 0); }
 inline float restated_cosf(float y) { return libm_sincosf(y, 1); }
 
+/* The prediction half of ElisionAudit: everything here is derived from the path's state BEFORE the step — the stream
+ * (copied), the depth, the ray — exactly what the kernels have when they decide (vmx_kernels.hip: step_is_dead,
+ * camera_step_ends, k_shade_ends). */
+struct StepPrediction {
+    bool last_mat, last_nomat, light_in_reach, throughput_finite;
+    V4 before, radiance_before;
+    V3 o, d;
+    template <class Rng>
+    void make(const orc_scene &sc, const Rng &stream, short depth, double r2scale, V3 ro, V3 rd, V4 accumColour,
+              V4 accumRadiance) {
+        Rng r = stream; /* a copy: the path's own stream is not advanced */
+        bool rr_end = false;
+        const int d1 = depth + 1;
+        if (d1 > 5) rr_end = r.u01() > 0.95f || d1 > 1000; /* :56-59 */
+        const double a = r.u01(), b = r.u01(), c = r.u01();
+        /* material (:98-165): draw a picks the mirror branch, then r1 = b, r2 = float(r2scale * c); sqrt(1 - r2) is NaN */
+        last_mat = rr_end || (!(a >= 0.96) && (1 - (float)(r2scale * c)) < 0);
+        /* no material (:166-196): r1 = a, r2 = r2scale * b in double */
+        last_nomat = rr_end || (1 - r2scale * b) < 0;
+        light_in_reach = false;
+        for (const vmx_sphere &s : sc.spheres)
+            if ((s.flags & VMX_SPHERE_EMIT) && sphere_hit(ro, rd, v3(s.centre[0], s.centre[1], s.centre[2]), s.radius) > 0.f)
+                light_in_reach = true;
+        throughput_finite = finite1(accumRadiance.x) && finite1(accumRadiance.y) && finite1(accumRadiance.z);
+        before = accumColour, radiance_before = accumRadiance, o = ro, d = rd;
+    }
+    static bool same_rgb(V4 p, V4 q) {
+        return std::memcmp(&p.x, &q.x, 4) == 0 && std::memcmp(&p.y, &q.y, 4) == 0 && std::memcmp(&p.z, &q.z, 4) == 0;
+    }
+    /* ended: Radiance returned in this step; else next_dir is the direction it goes on with */
+    void check(const orc_scene &sc, ElisionAudit &au, const CastOut &c, V3, V3, V4 after, bool ended, V3 next_dir) const {
+        au.steps++;
+        const bool last = c.material ? last_mat : last_nomat;
+        const bool all_nan = next_dir.x != next_dir.x && next_dir.y != next_dir.y && next_dir.z != next_dir.z;
+        if (last) {
+            au.predicted_last++;
+            /* an all-NaN direction misses the tree and every sphere: the next RayCast returns false, Radiance accumColour */
+            if (!ended && !all_nan) au.not_last++;
+            /* hitColour as the sphere table's entries up to the last light decide it, nothing else of the hit */
+            size_t prefix = 0;
+            for (size_t i = 0; i < sc.spheres.size(); ++i)
+                if (sc.spheres[i].flags & VMX_SPHERE_EMIT) prefix = i + 1;
+            float nearest = c.tri_id >= 0 ? c.tri_t : INFINITY;
+            V3 col = {0, 0, 0};
+            for (size_t i = 0; i < prefix; ++i) {
+                const vmx_sphere &s = sc.spheres[i];
+                const float t = sphere_hit(o, d, v3(s.centre[0], s.centre[1], s.centre[2]), s.radius);
+                if (t > 0.f && t < nearest) {
+                    nearest = t;
+                    if (s.flags & VMX_SPHERE_EMIT) col = v3(s.colour[0], s.colour[1], s.colour[2]);
+                }
+            }
+            if (throughput_finite) {
+                const V4 expect = before + radiance_before * V4{col.x, col.y, col.z, 0.f};
+                if (!same_rgb(expect, after)) au.colour_mismatch++;
+            }
+        }
+        if (last_mat && last_nomat && !light_in_reach && throughput_finite) {
+            au.predicted_dead++;
+            if (!same_rgb(before, after)) au.dead_changed++;
+            if (!ended && !all_nan) au.not_last++;
+        }
+    }
+};
+
 /* Radiance, pathtracer.cpp:21-198.  No texture is bound in any configuration
  * (pathtracer.cpp:63-66 not taken), so sampleColour is (1,1,1,1) (:75-79) unless a
  * texture was bound with orc_scene_bind_texture (then :63-66, VermiTexture::Sample). */
@@ -588,6 +666,8 @@ V4 radiance(const orc_scene &sc, V3 rStart, V3 rDir, Rng &rng, uint32_t sampling
     short depth = 0;
     const double r2scale = ((sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED) ? 1.0 : 10.0;
     const bool libm_double = (sampling & VMX_SAMPLING_LIBM_DOUBLE) != 0;
+    ElisionAudit *const audit = st ? st->audit : nullptr;
+    StepPrediction pred{};
     while (1) {
         bool is_ray = finite3(rDir); /* NaN directions are not rays */
         if (st) {
@@ -596,13 +676,23 @@ V4 radiance(const orc_scene &sc, V3 rStart, V3 rDir, Rng &rng, uint32_t sampling
             else if (is_ray)
                 st->rays_secondary++;
         }
+        if (audit) pred.make(sc, rng, depth, r2scale, rStart, rDir, accumColour, accumRadiance);
         CastOut c = ray_cast(sc, rStart, rDir, (st && count_nodes && is_ray) ? &st->cnt : nullptr);
-        if (!c.hit) return accumColour; /* :36-41 */
+        if (!c.hit) {
+            if (audit) pred.check(sc, *audit, c, rStart, rDir, accumColour, true, rDir);
+            return accumColour; /* :36-41 */
+        }
         if (st && c.tri_id >= 0) st->tri_hits++;
         accumColour = accumColour + accumRadiance * V4{c.colour.x, c.colour.y, c.colour.z, 0.f}; /* :43 */
         if (depth == 0) accumColour.w = c.distance;                                            /* :44-47 */
-        if (length(c.colour) > 1.f) return accumColour;                                        /* :52 */
-        if (++depth > 5 && (rng.u01() > 0.95f || depth > 1000)) return accumColour;            /* :56-59 */
+        if (length(c.colour) > 1.f) {
+            if (audit) pred.check(sc, *audit, c, rStart, rDir, accumColour, true, rDir);
+            return accumColour; /* :52 */
+        }
+        if (++depth > 5 && (rng.u01() > 0.95f || depth > 1000)) {
+            if (audit) pred.check(sc, *audit, c, rStart, rDir, accumColour, true, rDir);
+            return accumColour; /* :56-59 */
+        }
         V4 sampleColour = {0.f, 0.f, 0.f, 0.f}; /* :62 */
         if (c.material && sc.n_textures > 0)
             texture_sample(sc, c.uv, &sampleColour); /* :63-66 */
@@ -645,6 +735,7 @@ V4 radiance(const orc_scene &sc, V3 rStart, V3 rDir, Rng &rng, uint32_t sampling
             rStart = c.location - rDir * 0.001f;
             next_dir = dd;
         }
+        if (audit) pred.check(sc, *audit, c, rStart, rDir, accumColour, false, next_dir);
         rDir = next_dir;
         if (st && finite3(rDir)) st->continued++;
     }
@@ -1070,6 +1161,29 @@ void orc_radiance(const orc_scene *sc, const float *o, const float *d, uint32_t 
         stats->primary.continued = t_cont;
         stats->samples = n;
     }
+}
+
+/* ElisionAudit over n explicit camera rays (paths keyed like orc_radiance): out[6] = steps, predicted_last, predicted_dead,
+ * not_last, dead_changed, colour_mismatch; the radiance is written too and must equal orc_radiance's */
+void orc_audit_elision(const orc_scene *sc, const float *o, const float *d, uint32_t n, const vmx_opts *opts, float *out4,
+                       uint64_t *out6) {
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : a0, a1, a2, a3, a4, a5)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        Xoshiro rng;
+        rng.init(opts->seed, (uint32_t)i, 0);
+        (void)rng.next();
+        (void)rng.next();
+        ElisionAudit au;
+        PathStats st;
+        st.audit = &au;
+        V4 r = radiance(*sc, v3(o[i * 3], o[i * 3 + 1], o[i * 3 + 2]), v3(d[i * 3], d[i * 3 + 1], d[i * 3 + 2]), rng,
+                        opts->sampling, &st, false);
+        out4[i * 4] = r.x, out4[i * 4 + 1] = r.y, out4[i * 4 + 2] = r.z, out4[i * 4 + 3] = r.w;
+        a0 += au.steps, a1 += au.predicted_last, a2 += au.predicted_dead, a3 += au.not_last, a4 += au.dead_changed,
+            a5 += au.colour_mismatch;
+    }
+    out6[0] = a0, out6[1] = a1, out6[2] = a2, out6[3] = a3, out6[4] = a4, out6[5] = a5;
 }
 
 void orc_radiance_mt(const orc_scene *sc, const float *o, const float *d, uint32_t n,

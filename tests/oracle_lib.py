@@ -53,6 +53,7 @@ def lib(fast=False):
     l.orc_raycast.argtypes = [P, P, P, C.c_uint32, P]
     l.orc_radiance.argtypes = [P, P, P, C.c_uint32, C.POINTER(L.Opts), P, C.POINTER(L.Stats)]
     l.orc_radiance_mt.argtypes = [P, P, P, C.c_uint32, P, C.c_uint32, P]
+    l.orc_audit_elision.argtypes = [P, P, P, C.c_uint32, C.POINTER(L.Opts), P, P]
     l.orc_camera_matrix.argtypes = [C.POINTER(L.CameraDesc), P]
     l.orc_primary_rays.argtypes = [C.POINTER(L.CameraDesc), C.POINTER(L.Opts), C.c_uint32, P, P]
     l.orc_stream.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, P]
@@ -154,6 +155,15 @@ class OracleScene:
         self.l.orc_radiance(self.h, o.ctypes.data, d.ctypes.data, o.shape[0], C.byref(opts), out.ctypes.data,
                             C.byref(st))
         return out, st.as_dict()
+
+    def audit_elision(self, o, d, opts):
+        """ElisionAudit (oracle/vmx_oracle.cpp) over explicit camera rays: (radiance, dict of the six counters)"""
+        o, d = _f32(o), _f32(d)
+        out = np.empty((o.shape[0], 4), np.float32)
+        c = np.zeros(6, np.uint64)
+        self.l.orc_audit_elision(self.h, o.ctypes.data, d.ctypes.data, o.shape[0], C.byref(opts), out.ctypes.data, c.ctypes.data)
+        keys = ("steps", "predicted_last", "predicted_dead", "not_last", "dead_changed", "colour_mismatch")
+        return out, {k: int(v) for k, v in zip(keys, c)}
 
     def radiance_mt(self, o, d, seeds, sampling=0):
         o, d = _f32(o), _f32(d)

@@ -204,6 +204,46 @@ def test_reference_rng_and_keyed_rng_agree_statistically():
     assert l2 < 0.08  # per-pixel L2, Monte-Carlo noise at 256 spp
 
 
+def test_elision_argument_holds_on_the_oracle():
+    """The argument behind the kernels' two-phase shading and VMX_SAMPLING_ELIDE_DEAD, audited on the
+    oracle's own Radiance, step by step: from a copy of the stream taken BEFORE a step, predict that the step is the
+    path's last one for the material flag its hit turns out to have, and that no light sphere can colour it; then
+    check that the path did end there (or went on with an all-NaN direction), that accumColour moved by exactly
+    accumRadiance * (hitColour as the sphere table up to its last light decides it), and, where the step was predicted
+    last for both flag values with no light in reach, that accumColour did not move at all.  No violations — on the
+    reference's room, on tables with lights late and in view, with a texture (throughput != 1), in both samplings."""
+    pos, nrm, uv = scenes.cornell8()
+    c = scenes.cornell_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 96, 64, 16)
+    tables = [None,
+              va.spheres_array([
+                  dict(centre=(0, -5e7, 0), radius=5e7), dict(centre=(0, 5e7 + 1000, 0), radius=5e7),
+                  dict(centre=(0, 700, 300), radius=200, colour=(1.5, 1.2, 0.9), emit=True),
+                  dict(centre=(-5e7 + 2000, 0, 0), radius=5e7, normal_sign=-1),
+                  dict(centre=(300, 500, 400), radius=60, colour=(0.4, 0.1, 0.1), emit=True),  # weak: the path goes on
+                  dict(centre=(5e7 - 2000, 0, 0), radius=5e7, normal_sign=-1),
+                  dict(centre=(0, 0, -5e7 + 2000), radius=5e7, normal_sign=-1), dict(centre=(0, 0, 5e7 - 2000), radius=5e7)])]
+    tex = (np.random.RandomState(3).random_sample((8, 8, 3)) * 1.5).astype(np.float32)
+    for table in tables:
+        for textured in (False, True):
+            sc = O.OracleScene(pos, nrm, uv, spheres=table)
+            if textured:
+                sc.bind_texture(tex)
+            for sampling in (va.VMX_SAMPLING_PARITY, va.VMX_SAMPLING_CORRECTED):
+                opts = va.make_opts(seed=12, sampling=sampling)
+                o, d = O.primary_rays(cam, opts, 3)
+                ref, _ = sc.radiance(o, d, opts)
+                rad, au = sc.audit_elision(o, d, opts)
+                assert np.array_equal(bits(rad), bits(ref))  # the audit's hooks do not touch the computation
+                assert au["not_last"] == 0 and au["dead_changed"] == 0 and au["colour_mismatch"] == 0, (au, sampling, textured)
+                assert au["steps"] >= o.shape[0]
+                if sampling == va.VMX_SAMPLING_PARITY:  # r2 = 10 U: most steps end their path, most rays are not needed
+                    assert au["predicted_last"] > 0.8 * au["steps"] and au["predicted_dead"] > 0.7 * au["steps"], au
+                else:                                    # r2 = U: only Russian roulette, past depth 5
+                    assert 0 < au["predicted_last"] < 0.2 * au["steps"], au
+            sc.close()
+
+
 # ---- (c) committed golden fixtures ---------------------------------------------------
 @pytest.mark.parametrize("name", ["cornell8", "lattice"])
 def test_oracle_reproduces_golden(name):
