@@ -259,9 +259,10 @@ def test_first_generation_kernels_give_the_same_frames(sponza):
 
 
 def test_two_phase_shading_equals_one_phase(sponza):
-    """Split passes shade in two phases by default (k_shade_ends finishes the steps that end by their draws alone,
-    k_shade takes the rest in dense waves); vmx_opts.reserved[0] bit 8 asks for the one-phase form, and a call with
-    collect_counters always uses it.  Frames, ray counts, triangle-hit counts and continuation counts must agree —
+    """Split passes settle the Radiance steps that end by their draws alone apart from the others: by default in the
+    traversal kernel itself, which hands the other rays on as records (k_trace_w<.., SORT>; reference sampling only);
+    with vmx_opts.reserved[0] bit 9 in a first shading phase (k_shade_ends, the form `corrected` sampling uses);
+    bit 8 asks for plain one-phase shading, and a call with collect_counters always uses that.  Frames, ray counts, triangle-hit counts and continuation counts must agree —
     on the bench scene at 1080p, with bounce generations through both forms (tail_threshold=1: no fused tail), with a
     texture, and with a sphere table whose lights come after other spheres (SceneDev::emit_prefix)."""
     cam = sponza_cam(1920, 1080, 16)
@@ -270,8 +271,9 @@ def test_two_phase_shading_equals_one_phase(sponza):
             a, sa = sponza.render(cam, va.make_opts(seed=3, early_stop=es, **kw))
             b, sb = sponza.render(cam, va.make_opts(seed=3, early_stop=es, **dict(kw, pipeline=4 | 0x100)))
             c, sc_ = sponza.render(cam, va.make_opts(seed=3, early_stop=es, collect_counters=True, **kw))
-            assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c)), (es, kw)
-            for other in (sb, sc_):
+            d, sd = sponza.render(cam, va.make_opts(seed=3, early_stop=es, **dict(kw, pipeline=4 | 0x200)))
+            assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c)) and np.array_equal(bits(a), bits(d)), (es, kw)
+            for other in (sb, sc_, sd):
                 for key in ("samples", "samples_discarded", "rays_primary", "rays_secondary"):
                     assert sa[key] == other[key], (es, kw, key)
                 for stage in ("primary", "bounce"):
@@ -296,7 +298,7 @@ def test_two_phase_shading_equals_one_phase(sponza):
                 osc.bind_texture(tex)
             for sampling in (0, 1):
                 ref, rst = osc.render(cam, va.make_opts(seed=8, early_stop=False, sampling=sampling))
-                for pipe in (4, 4 | 0x100):
+                for pipe in (4, 4 | 0x100, 4 | 0x200):
                     for tail in (0, 1):
                         img, st = g.render(cam, va.make_opts(seed=8, early_stop=False, sampling=sampling, pipeline=pipe, tail_threshold=tail))
                         assert np.array_equal(bits(img), bits(ref)), (textured, sampling, pipe, tail)

@@ -39,7 +39,8 @@ for case in range(cases):
                             colour=tuple(float(v) for v in rng.uniform(0, 1, 3) * float(rng.choice([0.3, 1.0, 3.0]))),
                             emit=bool(rng.random() < 0.6), normal_sign=float(rng.choice([1, -1]))))
         spheres = va.spheres_array(tab)
-    kw = [{"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1}, {"pipeline": 4, "lds_entries": int(rng.choice([1, 3, 6, 40]))}, {}][rng.integers(0, 4)]
+    kw = [{"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1}, {"pipeline": 4, "lds_entries": int(rng.choice([1, 3, 6, 40]))}, {},
+          {"pipeline": 4 | 0x200, "tail_threshold": 1}, {"pipeline": 4 | 0x100, "tail_threshold": 1}][rng.integers(0, 6)]
     try:
         with va.Scene(pos, nrm, uv, spheres=spheres, leaf_size=leaf, builder=builder) as g:
             osc = O.OracleScene(pos, nrm, uv, spheres=spheres, leaf_size=leaf, tree=g.bvh() if builder else None)

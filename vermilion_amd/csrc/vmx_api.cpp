@@ -132,6 +132,8 @@ struct Workspace {
     DevBuf<unsigned int> full_u32;
     DevBuf<unsigned char> full_tmp;
     size_t full_words = 0, full_tmp_bytes = 0;
+    DevBuf<unsigned char> out_rec;   // k_trace_w<.., SORT>: 32-byte records of the camera rays that still need shading
+    DevBuf<unsigned int> out_count;
     DevBuf<unsigned char> accum;        // float4 per local pixel
     DevBuf<unsigned int> count, cursor, active[2], next_count;
     DevBuf<DevCounters> counters;
@@ -147,7 +149,7 @@ struct Workspace {
         accum.release(), count.release(), cursor.release(), active[0].release(), active[1].release();
         next_count.release(), counters.release(), out.release(), events.release();
         live_mask.release(), live_u32.release(), live_ids.release(), live_tmp.release();
-        full_mask.release(), full_u32.release(), full_tmp.release();
+        full_mask.release(), full_u32.release(), full_tmp.release(), out_rec.release(), out_count.release();
     }
 };
 
@@ -246,6 +248,7 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
     fr.r2scale = (o.sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
     fr.libm_double = (o.sampling & VMX_SAMPLING_LIBM_DOUBLE) ? 1u : 0u;
     fr.elide_dead = (o.sampling & VMX_SAMPLING_ELIDE_DEAD) ? 1u : 0u;  // split passes of vmx_render only (k_raygen)
+    fr.bounce_bits = 0;  // render_impl
     fr.world = o.world <= 1 ? 1u : o.world;
     fr.rank = o.world <= 1 ? 0u : o.rank;
     fr.stripe_rows = o.stripe_rows ? o.stripe_rows : 16u;
@@ -347,6 +350,7 @@ struct Tuning {
     uint32_t lds_entries, lds_primary, lds_bounce;  // LDS stack levels: fused kernels, camera-ray trace, bounce trace
     uint32_t sort_mode;  // bounce reordering: obits | dbits << 4 | dir_major << 8 | chunk_log2 << 12 | shade_sorted << 20
     bool two_phase;      // split passes of vmx_render: k_shade_ends + k_shade on what it queues (render_impl)
+    bool sorted;         // ... and the camera rays sorted by the trace kernel itself (k_trace_w<0, .., SORT>): no k_shade_ends
 };
 
 Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
@@ -361,6 +365,7 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.leaf_min = 0xFFFFFFFFu;
     tn.sort_mode = o->reserved[5];
     tn.two_phase = false;
+    tn.sorted = false;
     // LDS stack levels per lane (+1 scratch level), 512 B per level and wave.  Measured on the Sponza
     // stand-in: camera rays rarely go deep and gain from the 8th wave per SIMD that 8 levels leave
     // room for (52.6 -> 50.6 ms); the bounce kernel, once its record fetch is quad-cooperative, prefers
@@ -523,6 +528,10 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[3], int 
             launches += 2;
             break;
         }
+        if (tn.sorted) {  // the traversal kernel settles the rays whose step ends by its draws and hands the others on as records
+            wk.out_rec = ws.out_rec.p, wk.out_count = ws.out_count.p, wk.out_ctr = ctr;
+            HIP_TRY(hipMemsetAsync(ws.out_count.p, 0, 4, s));
+        }
         LAUNCH_TRY(launch_trace_q(sc->dev, fr, wk, nopx, pa, ctr, count, true, cfg, s));
         HIP_TRY(hipEventRecord(tl.b, s));
         timed.push_back(tl);
@@ -532,7 +541,9 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[3], int 
         HIP_TRY(hipEventRecord(ts.a, s));
         wk.qids = q_shade;
         const uint32_t max_chunks = (largest + 255) / 256;
-        if (tn.two_phase) {
+        if (tn.sorted) {
+            LAUNCH_TRY(launch_shade(sc->dev, fr, wk, nopx, pa, q[cur ^ 1], max_chunks, ctr, true, s));
+        } else if (tn.two_phase) {
             rc = shade_two_phase(sc, fr, wk, nopx, pa, q, q[cur ^ 1], max_chunks, (size_t)max_chunks * kSubQueues * 4, false, ctr, true, s);
             if (rc) return rc;
         } else {
@@ -626,7 +637,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     //   4 split wavefront for every pass (form 0 hands passes of fewer than 4 M paths to form 1's
     //     kernel, which needs no per-generation host round trip)
     const uint32_t pipeline = opts->reserved[0] & 0xFFu;  // (bit 8: one-phase shading, see two_phase below)
-    if (pipeline > 4 || (opts->reserved[0] & ~0x1FFu)) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    if (pipeline > 4 || (opts->reserved[0] & ~0x3FFu)) return fail(VMX_ERR_INVALID, "unknown pipeline form");
 #ifdef VMX_AB_KERNELS
     if (sc->dev.tex && pipeline >= 2 && pipeline <= 3)
         return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
@@ -646,6 +657,11 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     // for the one-phase form; the counting build keeps the one-phase form (an A/B of the two inside every test that
     // compares a counted with an uncounted call)
     tn.two_phase = !count && !(opts->reserved[0] & 0x100u);
+    // camera rays: the traversal kernel settles the rays whose step ends by its draws (and that no light sphere can
+    // colour) when they finish, and hands the others on as records; reserved[0] bit 9 keeps k_shade_ends for them.
+    // (r2 = U: hardly a step ends by its draws, the records would only add bytes)
+    tn.sorted = tn.two_phase && fr.r2scale == 10.0f && !(opts->reserved[0] & 0x200u);
+    fr.bounce_bits = tn.sorted ? 1u : 0u;
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
         return VMX_OK;
@@ -668,11 +684,11 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     uint64_t mem_budget = 0;
     const size_t n_pad_cap = ((size_t)npix + 63u) & ~(size_t)63u;
     if (!opts->samples_per_batch && !legacy) {
-        const size_t per_path = 16 + 64 + 8 + 16 + 8 + (sc->dev.tex ? 16 : 0) + (tn.sort_mode ? 12 : 0) + (fr.elide_dead ? 5 : 0);
+        const size_t per_path = 16 + 64 + 8 + 16 + 8 + (sc->dev.tex ? 16 : 0) + (tn.sort_mode ? 12 : 0) + (fr.elide_dead ? 5 : 0) + 32;
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const size_t held = ws.rayA.n + ws.state.n + ws.hit.n + ws.rad.n + ws.thr.n + (ws.ids[0].n + ws.ids[1].n + ws.ids[2].n) * 4 +
-                            (ws.sort_keys[0].n + ws.sort_keys[1].n + ws.ids_sorted.n) * 4;
+                            (ws.sort_keys[0].n + ws.sort_keys[1].n + ws.ids_sorted.n) * 4 + ws.out_rec.n + ws.live_ids.n * 4;
         mem_budget = (uint64_t)((free_b + held) / 10 * 9);
         if (const char *e = std::getenv("VMX_MEM_BUDGET_MB")) {
             const uint64_t cap = std::strtoull(e, nullptr, 10) << 20;
@@ -741,6 +757,11 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         if (ws.full_mask.ensure(words + 8) || ws.full_u32.ensure(2 * words + 16) || ws.full_tmp.ensure(tmp + 256))
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the two-phase shading lists");
         ws.full_words = words, ws.full_tmp_bytes = tmp;
+    }
+    if (split_any && tn.sorted) {
+        // every path of a pass may need a record; a wave pads at most one chunk of 256 (16 K waves at most)
+        if (ws.out_rec.ensure(((size_t)n_pad_max * smax + (4u << 20)) * 32) || ws.out_count.ensure(32))
+            return fail(VMX_ERR_NOMEM, "hipMalloc failed for the sorted camera-ray records");
     }
     size_t live_tmp_bytes = 0;
     if (elide) {
@@ -872,10 +893,15 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
                 LAUNCH_TRY(launch_raygen(sc->dev, fr, wk, px, pa, s));
                 HIP_TRY((hipError_t)launch_live_compact(ws.live_mask.p, cnt, nwords, offs, ws.live_ids.p, len, ws.live_tmp.p, live_tmp_bytes, s));
                 wk.live_ids = ws.live_ids.p, wk.live_count = len;
-                LAUNCH_TRY(launch_raygen_live(fr, wk, px, pa, s));
+                LAUNCH_TRY(launch_raygen_live(sc->dev, fr, wk, px, pa, s));
                 HIP_TRY(hipMemsetAsync(pa.rad_mask, 0, (size_t)nwords * 8, s));
             } else {
                 LAUNCH_TRY(launch_raygen(sc->dev, fr, wk, px, pa, s));
+            }
+            if (tn.sorted) {
+                wk.out_rec = ws.out_rec.p, wk.out_count = ws.out_count.p, wk.out_ctr = ws.counters.p;
+                HIP_TRY(hipMemsetAsync(ws.out_count.p, 0, 4, s));
+                if (!elide) HIP_TRY(hipMemsetAsync(pa.rad_mask, 0, (size_t)(((uint64_t)n_pad * S + 63) / 64) * 8, s));
             }
             HIP_TRY(hipEventRecord(tg.b, s));
             timed.push_back(tg);
@@ -888,7 +914,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             HIP_TRY(hipEventRecord(ts.a, s));
             // (under VMX_SAMPLING_ELIDE_DEAD the camera paths left are mostly those that go on: one phase — 0.56 against
             // 0.77 ms on the early-stop bench frame, no difference on the fixed-count one)
-            if (tn.two_phase && !elide) {
+            if (tn.two_phase && !elide && !tn.sorted) {
                 rc = shade_two_phase(sc, fr, wk, px, pa, qi, qi[0], 0, (size_t)(((uint64_t)n_pad * S + 63) / 64), false, ws.counters.p, false, s);
                 if (rc) return rc;
             } else {

@@ -104,6 +104,7 @@ struct FrameDev {
     float r2scale;                // 10 (parity) or 1 (corrected)
     uint32_t libm_double;         // VMX_SAMPLING_LIBM_DOUBLE: cos/sin(float r1) of pathtracer.cpp:162 as C's double functions
     uint32_t elide_dead;          // VMX_SAMPLING_ELIDE_DEAD: camera paths with provably zero radiance are not traced
+    uint32_t bounce_bits;         // k_shade stores step_bits of the next step with every bounce ray (k_trace_w<1, .., SORT>)
     uint32_t local_rows;          // rows owned by this rank
     uint32_t stripe_rows, rank, world;
     uint64_t seed;

@@ -74,6 +74,11 @@ struct WorkDev {
     unsigned int *live_cnt;
     const unsigned int *live_ids;
     const unsigned int *live_count;  // device scalar: entries of live_ids
+    // classified output of k_trace_w<.., SORT>: 32-byte records of the rays that still need shading,
+    // the number of list entries reserved so far (device scalar, multiple of 256), the frame's counters
+    void *out_rec;
+    unsigned int *out_count;
+    DevCounters *out_ctr;
     // two-phase shading: the ordered list of positions k_shade_ends left for k_shade (NULL: one phase)
     const unsigned int *flat_ids;
     const unsigned int *flat_count;
@@ -126,7 +131,7 @@ int query_paths_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, in
 int launch_camera_tables(const SceneDev &sc, uint32_t n_inner, float ox, float oy, float oz, void *cam_inner,
                          void *cam_tris, void *stream);
 int launch_raygen(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
-int launch_raygen_live(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
+int launch_raygen_live(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream);
 size_t live_compact_tmp_bytes(uint32_t nwords);
 int launch_live_compact(const unsigned long long *live_mask, const unsigned int *live_cnt, uint32_t nwords,
                         unsigned int *offs, unsigned int *ids, unsigned int *count, void *tmp, size_t tmp_bytes, void *stream);

@@ -423,6 +423,33 @@ __device__ __forceinline__ float sphere_hit_op(float opx, float opy, float opz, 
     }
     return th;
 }
+// sphere_hit_op(..., limit = infinity) > 0, without the two tests that need a finite limit (they never fire there)
+__device__ __forceinline__ bool sphere_in_reach(float opx, float opy, float opz, float C, float R2, float dx, float dy, float dz) {
+    const float B = dot3(opx, opy, opz, dx, dy, dz);
+    const float X = C - R2, BB = B * B;
+    constexpr float kRel = 9.5367431640625e-07f;  // 2^-20
+    const float tol_m = kRel * (C + R2 + BB);
+    const bool miss = BB < X - tol_m;
+    const bool behind = B < 0.f && B > -1e11f && X > tol_m;
+    const bool need = !(miss || behind);
+    bool reach = false;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+        const double b = (double)B;
+        double det = b * b - (double)C + (double)R2;
+        float v = 0.f;
+        if (!(det < 0)) {
+            det = sqrt(det);
+            double t = b - det;
+            if (t > 1e-4) v = (float)t;
+            else {
+                t = b + det;
+                if (t > 1e-4) v = (float)t;
+            }
+        }
+        reach = need && v > 0.f;
+    }
+    return reach;
+}
 __device__ __forceinline__ float sphere_hit(float ox, float oy, float oz, float dx, float dy, float dz,
                                             float4 geom /* centre, rad*rad */, float limit) {
     const float opx = geom.x - ox, opy = geom.y - oy, opz = geom.z - oz;
@@ -723,10 +750,14 @@ __device__ __forceinline__ bool path_shade_end(Path &P, const CastResult &c, Ste
 // nothing nearer yet (limit = infinity).  Then accumColour after the step equals accumColour before it bit for bit
 // (x + t * 0 == x for finite t), so the ray need not be traced: with the reference's r2 = 10 U that is 78 % of all rays.
 // (Nothing is ever elided under VMX_SAMPLING_CORRECTED: r2 = U never exceeds 1.)
-template <bool TEX, bool LDS_GEOM>
-__device__ __forceinline__ bool step_is_dead(const SceneDev &sc, float r2scale, Rng rng, uint32_t depth, float ox, float oy,
-                                             float oz, float dx, float dy, float dz, float tr, float tg, float tb,
-                                             const float4 *geom = nullptr) {
+// The same facts as three bits — what the kernels pass along with a ray:
+//   bit 0  the step is the path's last one if its hit has a material   (Russian roulette, or the draws of :98 / :156)
+//   bit 1  ... if its hit has none                                      (Russian roulette, or the draw of :170)
+//   bit 2  some light sphere passes sphereIntersect > 0 for the ray with nothing nearer yet: hitColour may be non-zero
+// (bits 0 and 1 are left clear for a path whose throughput is not finite: inf * 0 would be NaN, the step is shaded in full)
+template <bool TEX>
+__device__ __forceinline__ uint32_t step_bits(const SceneDev &sc, float r2scale, Rng rng, uint32_t depth, float ox, float oy,
+                                              float oz, float dx, float dy, float dz, float tr, float tg, float tb) {
     bool rr_end = false;
     if (depth + 1u > 5u) {
         const double rr = rng_u01(rng);
@@ -734,30 +765,25 @@ __device__ __forceinline__ bool step_is_dead(const SceneDev &sc, float r2scale, 
     }
     const double a = rng_u01(rng), b = rng_u01(rng), c = rng_u01(rng);
     const float r2m = (float)((double)r2scale * c);
-    const bool ends_mat = !(a >= 0.96) && (1.0f - r2m) < 0.0f;
-    const bool ends_nomat = (1.0 - (double)r2scale * b) < 0.0;
-    bool dead = rr_end || (ends_mat && ends_nomat);
-    if (TEX && !finite3(tr, tg, tb)) dead = false;  // inf * 0 would be NaN
-    for (uint32_t i = 0; i < sc.nspheres; ++i) {
+    bool ends_mat = rr_end || (!(a >= 0.96) && (1.0f - r2m) < 0.0f);
+    bool ends_nomat = rr_end || (1.0 - (double)r2scale * b) < 0.0;
+    if (TEX && !finite3(tr, tg, tb)) ends_mat = ends_nomat = false;
+    bool light = false;
+    for (uint32_t i = 0; i < sc.emit_prefix; ++i) {
         const SphereDev &q = sc.spheres[i];
-        if ((q.flags & 1u) && __builtin_amdgcn_ballot_w64(dead) != 0) {
-            const float4 g = LDS_GEOM ? geom[i] : make_float4(q.cx, q.cy, q.cz, q.rad2);
-            const float th = sphere_hit(ox, oy, oz, dx, dy, dz, g, kInf);
-            if (th > 0.f) dead = false;
+        if (q.flags & 1u) {
+            const float opx = q.cx - ox, opy = q.cy - oy, opz = q.cz - oz;
+            if (sphere_in_reach(opx, opy, opz, dot3(opx, opy, opz, opx, opy, opz), q.rad2, dx, dy, dz)) light = true;
         }
     }
-    return dead;
+    return (ends_mat ? 1u : 0u) | (ends_nomat ? 2u : 0u) | (light ? 4u : 0u);
 }
-
-// The draws that decide whether a Radiance step is the path's last one whatever it hits (see step_is_dead), for the camera
-// step (depth 0: no Russian roulette): bit 0 = it ends if the hit has a material, bit 1 = it ends if it has none.
-// k_raygen leaves them in the ray record's fourth word; k_shade_ends reads them instead of re-keying the stream.
-__device__ __forceinline__ uint32_t camera_step_ends(float r2scale, Rng rng) {
-    const double a = rng_u01(rng), b = rng_u01(rng), c = rng_u01(rng);
-    const float r2m = (float)((double)r2scale * c);
-    const bool ends_mat = !(a >= 0.96) && (1.0f - r2m) < 0.0f;
-    const bool ends_nomat = (1.0 - (double)r2scale * b) < 0.0;
-    return (ends_mat ? 1u : 0u) | (ends_nomat ? 2u : 0u);
+template <bool TEX, bool LDS_GEOM>
+__device__ __forceinline__ bool step_is_dead(const SceneDev &sc, float r2scale, Rng rng, uint32_t depth, float ox, float oy,
+                                             float oz, float dx, float dy, float dz, float tr, float tg, float tb,
+                                             const float4 *geom = nullptr) {
+    (void)geom;
+    return step_bits<TEX>(sc, r2scale, rng, depth, ox, oy, oz, dx, dy, dz, tr, tg, tb) == 3u;
 }
 
 // Radiance's loop body after RayCast in one piece (the fused kernels)
@@ -863,9 +889,10 @@ __device__ __forceinline__ void rng_load(const PathArrays &pa, uint32_t pid, Rng
     r.s2 = (uint64_t)__float_as_uint(f.x) | ((uint64_t)__float_as_uint(f.y) << 32);
     r.s3 = (uint64_t)__float_as_uint(f.z) | ((uint64_t)__float_as_uint(f.w) << 32);
 }
-__device__ __forceinline__ void ray_store(const PathArrays &pa, uint32_t pid, const Path &P) {
+// bits: step_bits of the step that will trace this ray (k_trace_w<1, .., SORT> reads them back); 0 = "shade it in full"
+__device__ __forceinline__ void ray_store(const PathArrays &pa, uint32_t pid, const Path &P, uint32_t bits = 0) {
     ((float4 *)pa.state)[(size_t)pid * 4] = make_float4(P.ox, P.oy, P.oz, P.dx);
-    ((float4 *)pa.state)[(size_t)pid * 4 + 1] = make_float4(P.dy, P.dz, __uint_as_float(P.depth), 0.f);
+    ((float4 *)pa.state)[(size_t)pid * 4 + 1] = make_float4(P.dy, P.dz, __uint_as_float(P.depth), __uint_as_float(bits));
 }
 __device__ __forceinline__ void ray_load(const PathArrays &pa, uint32_t pid, Path &P) {
     const float4 a = ((const float4 *)pa.state)[(size_t)pid * 4], b = ((const float4 *)pa.state)[(size_t)pid * 4 + 1];
@@ -1406,7 +1433,7 @@ __global__ void k_camera_tables(SceneDev sc, uint32_t n_inner, float ox, float o
 // k_raygen — camera rays of one pass (pathtracer.cpp:251-280), written to rayA[pid] as
 // (direction, flag word): all camera rays share the frame's origin, so 16 bytes per ray suffice.
 // Slots without a sample (past the pixel's last one, padding) get the word ~0 and are skipped downstream;
-// the others the two camera_step_ends bits of their first Radiance step.
+// the others the two step_bits of their first Radiance step.
 // ---------------------------------------------------------------------------
 // LIVE 0: every camera ray of the pass, rayA[pid].   LIVE 1 (VMX_SAMPLING_ELIDE_DEAD): nothing is written but one word
 // of live bits and its popcount per 64 consecutive path ids; launch_live_compact turns those into the ordered list of
@@ -1433,7 +1460,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
                     Rng rng;
                     primary_ray(fr, global_pixel(fr, lp), k, rng, dx, dy, dz);
                     if (LIVE) live = !step_is_dead<false, false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
-                    else depth = camera_step_ends(fr.r2scale, rng);
+                    else depth = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
                 }
                 if (!LIVE) ((float4 *)pa.rayA)[pid0 + lane] = make_float4(dx, dy, dz, __uint_as_float(depth));
             } else if (!LIVE) {  // padding slots of the pass: marked like sample slots past a pixel's last sample
@@ -1459,10 +1486,10 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
             if (LIVE) live = !step_is_dead<false, false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
-            else depth = camera_step_ends(fr.r2scale, rng);
+            else depth = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
         }
         // camera rays share the origin (FrameDev): one 16-byte record in rayA — direction, and a word that is ~0 for a
-        // slot without a sample (past the pixel's last one, or padding), else the step's camera_step_ends bits
+        // slot without a sample (past the pixel's last one, or padding), else the step's step_bits
         if (!LIVE) ((float4 *)pa.rayA)[pid] = make_float4(dx, dy, dz, __uint_as_float(depth));
         if (LIVE) {
             const unsigned long long bits = __builtin_amdgcn_ballot_w64(live);
@@ -1473,7 +1500,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
 
 // the rays of the live camera paths, in list order: rayA[i] belongs to path live_ids[i]
 __global__ void __launch_bounds__(256)
-k_raygen_live(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
+k_raygen_live(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
     const uint32_t n = *wk.live_count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t pid = wk.live_ids[i];
@@ -1486,7 +1513,7 @@ k_raygen_live(FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) {
         if (primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {  // (always: the path was found live from the same item)
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
-            depth = camera_step_ends(fr.r2scale, rng);
+            depth = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
         }
         ((float4 *)pa.rayA)[i] = make_float4(dx, dy, dz, __uint_as_float(depth));
     }
@@ -1585,7 +1612,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                         if (SRC == 0) {  // camera ray: (direction, flag word), origin from the frame
                             const float4 a = ((const float4 *)pa.rayA)[pid];
                             ox = fr.px, oy = fr.py, oz = fr.pz, dx = a.x, dy = a.y, dz = a.z;
-                            depth = __float_as_uint(a.w) == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u;  // (else: camera_step_ends bits)
+                            depth = __float_as_uint(a.w) == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u;  // (else: step_bits)
                         } else {
                             const float4 a = ((const float4 *)pa.state)[(size_t)pid * 4], b = ((const float4 *)pa.state)[(size_t)pid * 4 + 1];
                             ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
@@ -2002,7 +2029,14 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
 
 // LIVE (SRC 0, VMX_SAMPLING_ELIDE_DEAD): the work is the dense list of live camera paths — ray and hit record of list
 // entry i sit at rayA[i] / hit[i] — cut into 8 bands of whole waves (live_band)
-template <int SRC, bool LIVE = false>
+// SORT (classified output): instead of a hit record per ray, the finished rays of a wave are sorted on the
+// spot when the wave refills.  A ray whose Radiance step is the path's last one by the path's own draws (the bits that
+// came with the ray) and that cannot meet a light sphere needs nothing more: it is counted here and forgotten.  The
+// others get a 32-byte record (direction, flag word | t, leaf slot, position) appended to a dense list — the wave
+// reserves 256 entries at a time with one atomic and pads what it leaves unused with position = ~0 — which k_shade
+// reads front to back.
+constexpr uint32_t kOutChunk = 256;
+template <int SRC, bool LIVE = false, bool SORT = false>
 __global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(VMX_TRACE_SGPRS)))
 k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     extern __shared__ uint2 lds_stack[];
@@ -2034,10 +2068,46 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
     float ix = 0.f, iy = 0.f, iz = 0.f, best = 0.f;
     int slot = -1, sp = 0;
     uint32_t cur = kIdle, pid = 0;
+    // SORT: the ray's flag word; bit 31 set while the lane holds a finished ray that has not been sorted yet
+    uint32_t rflags = 0;
+    uint32_t out_lo = 0, out_hi = 0, n_rays = 0, n_hits = 0;  // (wave-uniform) reserved list entries; rays / triangle hits settled here
     // camera rays: direction octant of the wave's rays if they all share it (else 8): selects the
     // per-octant copy of the node table (k_camera_tables) for wave-uniform steps
     uint32_t wave_octant = 8;
     stk[0] = make_uint2(kBottom, 0xFF800000u);  // bottom entry; pushes start at level 1, so it stays
+
+    // SORT: settle the finished rays the wave's lanes hold (wave-uniform code: called before a refill and at the end)
+    auto sort_finished = [&]() {
+        const bool fin = (rflags >> 31) != 0;
+        const bool material = slot >= 0;
+        // ends by its draws (bit 0 / 1 by the material flag) and no light sphere in reach (bit 2): nothing to shade
+        const bool done = fin && (((material ? rflags : rflags >> 1) & 1u) != 0) && (rflags & 4u) == 0;
+        // (a bounce "ray" with a non-finite direction is traced like the others but is not counted as a ray: tally_add)
+        const bool counted = SRC == 0 || finite3(dx, dy, dz);
+        n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(done && counted));
+        n_hits += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(done && counted && material));
+        const bool todo = fin && !done;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(todo);
+        const uint32_t n = (uint32_t)__popcll(m);
+        float4 *__restrict__ rec = (float4 *)wk.out_rec;
+        if (n != 0) {
+            constexpr uint32_t kRec = SRC == 0 ? 2 : 1;  // float4s per entry; the last one holds (t, leaf slot, position, -)
+            if (n > out_hi - out_lo) {  // pad what is left of the chunk, take a new one
+                if (lane < out_hi - out_lo) rec[(size_t)(out_lo + lane) * kRec + (kRec - 1)] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(wk.out_count, kOutChunk);
+                out_lo = __builtin_amdgcn_readfirstlane(base);
+                out_hi = out_lo + kOutChunk;
+            }
+            if (todo) {
+                const size_t at = (size_t)(out_lo + (uint32_t)__popcll(m & lt_mask)) * kRec;
+                if (SRC == 0) rec[at] = make_float4(dx, dy, dz, __uint_as_float(rflags & 7u));  // (bounce paths: ray and stream are in state[pid])
+                rec[at + (kRec - 1)] = make_float4(best, __int_as_float(slot), __uint_as_float(pid), 0.f);
+            }
+            out_lo += n;
+        }
+        rflags &= 0x7FFFFFFFu;
+    };
 
     // One traversal step of every active lane.  The NaN-exact box form runs only while one of the
     // wave's rays needs it.
@@ -2231,7 +2301,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             } while (__uint_as_float(e.y) > best);
             cur = e.x;
             if (cur == kBottom) {
-                hit_out[pid] = make_float2(best, __int_as_float(slot));
+                if (SORT) rflags |= 0x80000000u;  // settled at the next refill (the lane keeps t, slot, direction until then)
+                else hit_out[pid] = make_float2(best, __int_as_float(slot));
                 cur = kIdle;
             }
         }
@@ -2241,6 +2312,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         // ---- refill idle lanes -------------------------------------------------------
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(cur == kIdle);
         if (idle != 0 && !exhausted && ((uint32_t)__popcll(idle) >= refill_min || idle == ~0ull)) {
+            if (SORT) sort_finished();
             for (;;) {
                 if (res_lo == res_hi) {
                     uint32_t lim = SRC == 0 ? band_items : min(wk.qids.counts[src * 32], wk.qids.sub_capacity);
@@ -2292,10 +2364,12 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                             const float4 a = ((const float4 *)pa.rayA)[pid];
                             ox = fr.px, oy = fr.py, oz = fr.pz, dx = a.x, dy = a.y, dz = a.z;
                             valid = __float_as_uint(a.w) != 0xFFFFFFFFu;  // sample slot past the pixel's last sample
+                            if (SORT && valid) rflags = __float_as_uint(a.w) & 7u;
                         } else {
                             const float4 a = ((const float4 *)pa.state)[(size_t)pid * 4], b = ((const float4 *)pa.state)[(size_t)pid * 4 + 1];
                             ox = a.x, oy = a.y, oz = a.z, dx = a.w, dy = b.x, dz = b.y;
                             valid = __float_as_uint(b.z) != 0xFFFFFFFFu;
+                            if (SORT && valid) rflags = __float_as_uint(b.w) & 7u;  // k_shade: step_bits of this step
                         }
                     }
                     if (valid) {
@@ -2375,6 +2449,16 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         prof_t = __builtin_readcyclecounter();
 #endif
     }
+    if (SORT) {
+        sort_finished();
+        float4 *__restrict__ rec = (float4 *)wk.out_rec;
+        constexpr uint32_t kRec = SRC == 0 ? 2 : 1;
+        for (uint32_t i = out_lo + lane; i < out_hi; i += 64u) rec[(size_t)i * kRec + (kRec - 1)] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
+        if (lane == 0) {
+            if (n_rays) atomicAdd(&wk.out_ctr->stage[SRC].rays, (unsigned long long)n_rays);
+            if (n_hits) atomicAdd(&wk.out_ctr->stage[SRC].tri_hits, (unsigned long long)n_hits);
+        }
+    }
 #ifdef VMX_STEP_PROFILE
     if (lane < 20) atomicAdd(&g_step_prof[SRC][lane >> 1][lane & 1], s_prof[wave][lane >> 1][lane & 1]);
     if (lane == 0) {
@@ -2400,7 +2484,9 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
 #define VMX_SHADE_WPS 7  // waves per SIMD k_shade is compiled for (<= 72 VGPRs): left to itself hipcc takes 100 (5 waves) since the
                         // cosf/sinf path came in; k_shade<0> 14.6 ms at 5-6 waves (the cap at 6 spills into the hot path), 13.1 at 7, 13.4 at 8
 #endif
-template <int SRC, bool TEX, bool ELIDE = false, bool FROMQ = false>
+// FROMQ: 0 every path of the generation; 1 the ordered list of positions k_shade_ends + launch_live_compact left
+// (wk.flat_ids); 2 the records k_trace_w<.., SORT> appended (wk.out_rec: ray, hit and position in one place)
+template <int SRC, bool TEX, bool ELIDE = false, int FROMQ = 0>
 __global__ void __launch_bounds__(256, VMX_SHADE_WPS)
 k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, IdQueue qout, uint32_t max_chunks,
         DevCounters *ctr) {
@@ -2421,23 +2507,33 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
     // into rayA / hit for camera paths (`src`), a place in the id queue for bounce paths
     uint32_t items = (SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues);
     uint32_t flat_n = 0;
-    if (FROMQ) flat_n = *wk.flat_count, items = (flat_n + blockDim.x - 1) / blockDim.x;
+    if (FROMQ == 1) flat_n = *wk.flat_count, items = (flat_n + blockDim.x - 1) / blockDim.x;
+    if (FROMQ == 2) flat_n = *wk.out_count, items = (flat_n + blockDim.x - 1) / blockDim.x;
     // VMX_SAMPLING_ELIDE_DEAD: the pass's live camera paths only; ray and hit record sit at the list position `src`
     constexpr bool listed = SRC == 0 && ELIDE;
     uint32_t live_n = 0;
     if (listed) {
         live_n = *wk.live_count;
-        if (!FROMQ) items = (live_n + blockDim.x - 1) / blockDim.x;
+        if (FROMQ == 0) items = (live_n + blockDim.x - 1) / blockDim.x;
     }
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
         bool run;
         uint32_t pid = 0, src = 0;
+        float2 hrec = make_float2(0.f, 0.f);  // FROMQ 2: the hit record came with the list entry
         Path P;
         if (SRC == 0) {
             src = pid = item * blockDim.x + threadIdx.x;
-            if (FROMQ) {
+            float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0;
+            if (FROMQ == 1) {
                 src = pid = src < flat_n ? wk.flat_ids[src] : 0xFFFFFFFFu;
                 if (listed) live_n = 0xFFFFFFFFu;  // (a listed position is a valid one)
+            }
+            if (FROMQ == 2) {  // (direction, flag word)(t, leaf slot, position, -); position ~0: padding of a chunk
+                const bool in = src < flat_n;
+                if (in) rec0 = ((const float4 *)wk.out_rec)[(size_t)src * 2], rec1 = ((const float4 *)wk.out_rec)[(size_t)src * 2 + 1];
+                src = pid = in ? __float_as_uint(rec1.z) : 0xFFFFFFFFu;
+                hrec = make_float2(rec1.x, rec1.y);
+                if (listed) live_n = 0xFFFFFFFFu;
             }
             if (listed) pid = src < live_n ? wk.live_ids[src] : 0xFFFFFFFFu;  // (no such path: j >= samples below)
             uint32_t j, s_idx;
@@ -2447,7 +2543,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             run = j < wk.samples && s_idx < wk.n_pad && primary_item(fr, wk, px, j, s_idx, pid2, pixel, k);
             if (run) {
                 // the ray comes from k_raygen; the stream is re-keyed and its two jitter draws skipped
-                const float4 a = ((const float4 *)pa.rayA)[src];
+                const float4 a = FROMQ == 2 ? rec0 : ((const float4 *)pa.rayA)[src];
                 P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz, P.dx = a.x, P.dy = a.y, P.dz = a.z, P.depth = 0;
                 rng_init(P.rng, fr.seed, pixel, k);
                 (void)rng_next(P.rng);
@@ -2459,16 +2555,23 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
         } else {
             uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
             uint32_t pos = chunk * blockDim.x + threadIdx.x;
-            if (FROMQ) {  // a listed position = (block item of k_shade_ends) * 256 + lane
+            if (FROMQ == 1) {  // a listed position = (block item of k_shade_ends) * 256 + lane
                 const uint32_t at = item * blockDim.x + threadIdx.x;
                 run = at < flat_n;
                 const uint32_t p = run ? wk.flat_ids[at] : 0u;
                 sub = (p >> 8) % kSubQueues, chunk = (p >> 8) / kSubQueues, pos = chunk * 256u + (p & 255u);
+            } else if (FROMQ == 2) {  // (t, leaf slot, path id, -); path id ~0: padding of a chunk
+                const uint32_t at = item * blockDim.x + threadIdx.x;
+                float4 r = make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
+                if (at < flat_n) r = ((const float4 *)wk.out_rec)[at];
+                pid = __float_as_uint(r.z);
+                hrec = make_float2(r.x, r.y);
+                run = pid != 0xFFFFFFFFu;
             } else {
                 run = pos < min(wk.qids.counts[sub * 32], wk.qids.sub_capacity);
             }
             if (run) {
-                pid = wk.qids.ids[(size_t)sub * wk.qids.sub_capacity + pos];
+                if (FROMQ != 2) pid = wk.qids.ids[(size_t)sub * wk.qids.sub_capacity + pos];
                 path_load_arrays<TEX>(pa, pid, P);
             }
         }
@@ -2481,7 +2584,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             P.dest = pid;
             depth0 = P.depth == 0 ? 1u : 0u;
             fl.was_ray = depth0 ? true : finite3(P.dx, P.dy, P.dz);
-            const float2 h = hits[SRC == 0 ? src : pid];
+            const float2 h = FROMQ == 2 ? hrec : hits[SRC == 0 ? src : pid];
             cast_finish<true, SRC == 0>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom,
                                         s_cam_op);
             st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
@@ -2499,7 +2602,9 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             step_is_dead<TEX, true>(sc, fr.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb, s_geom))
             alive = false, fl.continues = false;  // VMX_SAMPLING_ELIDE_DEAD: the next ray cannot change the path's colour
         if (alive) {
-            ray_store(pa, pid, P);
+            uint32_t bits = 0;
+            if (fr.bounce_bits) bits = step_bits<TEX>(sc, fr.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb);
+            ray_store(pa, pid, P, bits);
             rng_store(pa, pid, P.rng);
             if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, 1.f);
         }
@@ -2509,7 +2614,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             // aligned word of the mask (path ids of an item are consecutive, 256 per block)
             const bool need = run && (alive || P.ar != 0.f || P.ag != 0.f || P.ab != 0.f);
             if (need) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
-            if (listed || FROMQ) {  // the mask was cleared for the pass / written by k_shade_ends; neighbours share words
+            if (listed || FROMQ != 0) {  // the mask was cleared for the pass / written by k_shade_ends; neighbours share words
                 if (need) atomicOr(&pa.rad_mask[pid >> 6], 1ull << (pid & 63u));
             } else {
                 const unsigned long long word = __builtin_amdgcn_ballot_w64(need);
@@ -2535,7 +2640,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
 // makes the ordered list of them) for k_shade, which then runs in dense waves.  Same colours, same counters.
 // (k_shade alone does the same work with four lanes in five idle behind the branch: 13.1 ms against 3.9 + 4 here
 // for the 530.8 M camera paths of the bench frame.)
-//   SRC 0: camera paths; the two "ends" bits come with the ray record (k_raygen: camera_step_ends)
+//   SRC 0: camera paths; the two "ends" bits come with the ray record (k_raygen: step_bits)
 //   SRC 1: queued bounce paths; the draws are read off a copy of the path's stream
 //   LISTED (SRC 0, VMX_SAMPLING_ELIDE_DEAD): the pass's live-path list instead of all its path ids
 // ---------------------------------------------------------------------------
@@ -3188,12 +3293,12 @@ int launch_raygen(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pix
     return launch_status();
 }
 
-int launch_raygen_live(const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream) {
+int launch_raygen_live(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa, void *stream) {
     // the list's length is known on the device only: a grid for a third of the pass's paths, striding over the rest
     const uint64_t total = ((uint64_t)wk.samples * wk.n_pad + 2) / 3;
     uint32_t grid = (uint32_t)std::min<uint64_t>((total + 255) / 256, 256u * 32u);
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(k_raygen_live, dim3(grid), dim3(256), 0, (hipStream_t)stream, fr, wk, px, pa);
+    hipLaunchKernelGGL(k_raygen_live, dim3(grid), dim3(256), 0, (hipStream_t)stream, sc, fr, wk, px, pa);
     return launch_status();
 }
 
@@ -3203,8 +3308,13 @@ int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pi
     dim3 g(cfg.grid), b(cfg.block);
     // production form: k_trace_w; with counters: the first form k_trace_q (same tests per ray)
     if (!count) {
-        if (from_queue) hipLaunchKernelGGL((k_trace_w<1>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
-        else if (wk.live_ids) hipLaunchKernelGGL((k_trace_w<0, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
+        if (from_queue) {
+            if (wk.out_rec) hipLaunchKernelGGL((k_trace_w<1, false, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
+            else hipLaunchKernelGGL((k_trace_w<1>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
+        } else if (wk.out_rec) {
+            if (wk.live_ids) hipLaunchKernelGGL((k_trace_w<0, true, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
+            else hipLaunchKernelGGL((k_trace_w<0, false, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
+        } else if (wk.live_ids) hipLaunchKernelGGL((k_trace_w<0, true>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
         else hipLaunchKernelGGL((k_trace_w<0>), g, b, cfg.lds_bytes, s, sc, fr, wk, pa);
     } else {
         if (from_queue) hipLaunchKernelGGL((k_trace_q<true, 1>), g, b, cfg.lds_bytes, s, sc, fr, wk, px, pa, counters);
@@ -3232,7 +3342,7 @@ int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, 
 int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                  IdQueue qout, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    const bool flat = wk.flat_ids != nullptr;  // second phase: the list's length is known on the device only -> a full grid
+    const bool flat = wk.flat_ids != nullptr || wk.out_rec != nullptr;  // a list whose length is known on the device only -> a full grid
     // 7 blocks per CU are resident (VMX_SHADE_WPS); more blocks only add end-of-block counter atomics, which a small pass
     // feels (early-stop frame, first pass: 1.70 ms with 4096 blocks, 1.05 with 1792; the bench frame's 530.8 M paths: no change)
     constexpr uint32_t kShadeGrid = 256u * VMX_SHADE_WPS;
@@ -3249,14 +3359,18 @@ int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pixe
     // camera paths are shaded from the live list exactly when render_impl built one (wk.live_ids)
     const bool elide = from_queue ? fr.elide_dead != 0 : wk.live_ids != nullptr;
     if (from_queue) {
-        if (flat) { if (elide) VMX_GO_T(1, true, true); else VMX_GO_T(1, false, true); }
-        else { if (elide) VMX_GO_T(1, true, false); else VMX_GO_T(1, false, false); }
+        if (wk.out_rec) { if (elide) VMX_GO_T(1, true, 2); else VMX_GO_T(1, false, 2); }
+        else if (flat) { if (elide) VMX_GO_T(1, true, 1); else VMX_GO_T(1, false, 1); }
+        else { if (elide) VMX_GO_T(1, true, 0); else VMX_GO_T(1, false, 0); }
+    } else if (wk.out_rec) {
+        if (elide) VMX_GO_T(0, true, 2);
+        else VMX_GO_T(0, false, 2);
     } else if (flat) {
-        if (elide) VMX_GO_T(0, true, true);
-        else VMX_GO_T(0, false, true);
+        if (elide) VMX_GO_T(0, true, 1);
+        else VMX_GO_T(0, false, 1);
     } else {
-        if (elide) VMX_GO_T(0, true, false);
-        else VMX_GO_T(0, false, false);
+        if (elide) VMX_GO_T(0, true, 0);
+        else VMX_GO_T(0, false, 0);
     }
 #undef VMX_GO_T
 #undef VMX_GO
