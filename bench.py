@@ -46,10 +46,12 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 A_INNER = {"trace_camera": 20, "trace_bounce": 44}
 A_TRI = {"trace_camera": 36, "trace_bounce": 53}
 KERNEL_TEXT = {
-    "trace_camera": "k_trace_w<0> (persistent BVH traversal of the camera rays)",
-    "trace_bounce": "k_trace_w<1> (persistent BVH traversal of a bounce generation, quad-cooperative record fetch)",
-    "shade_camera": "k_shade_ends<0> + list compaction + k_shade<0> (RayCast tail + Radiance step of the camera rays, two phases)",
-    "shade_bounce": "k_shade_ends<1> + list compaction + k_shade<1>", "tail": "k_paths<2> (fused tail of the last bounce generations)",
+    "trace_camera": "k_trace_w<0, SORT> (persistent BVH traversal of the camera rays; settles the rays whose step ends by its draws, "
+                    "hands the others on as records)",
+    "trace_bounce": "k_trace_w<1, SORT> (persistent BVH traversal of a bounce generation, quad-cooperative record fetch; sorts its "
+                    "finished rays like the camera kernel)",
+    "shade_camera": "k_shade<0> on the records the camera kernel handed on (RayCast tail + Radiance step)",
+    "shade_bounce": "k_shade<1> on the records the bounce kernel handed on", "tail": "k_paths<2> (fused tail of the last bounce generations)",
     "raygen": "k_raygen", "resolve": "k_resolve", "fused": "k_paths<0>",
 }
 
@@ -338,6 +340,8 @@ def main():
             exact frame, profiles/counters.json) / the launch duration measured here"""
             n = max(klaunch[name], 1)
             avg_ms = kms[name] * args.steps / n
+            if n > args.steps:  # several launches per step: the counters are those of the longest one, so is the duration
+                avg_ms = sum(s["kernels"][name]["longest_ms"] for s in stats) / args.steps
             r = {"kernel": KERNEL_TEXT.get(name, name), "avg_launch_ms": round(avg_ms, 4),
                  "launches_per_step": n // max(args.steps, 1), "ms_per_step": round(kms[name], 3)}
             d = (prof or {}).get(name, {}).get("derived")

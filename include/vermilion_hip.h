@@ -149,9 +149,9 @@ typedef struct vmx_stats {
  * a scene: what bench.py's roofline object is computed from (the dominant kernel of a step) */
 #define VMX_K_RAYGEN 0        /* k_raygen (+ live-path list under VMX_SAMPLING_ELIDE_DEAD)  */
 #define VMX_K_TRACE_CAMERA 1  /* k_trace_w<0>: BVH traversal of the camera rays            */
-#define VMX_K_SHADE_CAMERA 2  /* k_shade_ends<0> + list compaction + k_shade<0> (one interval) */
+#define VMX_K_SHADE_CAMERA 2  /* k_shade<0> (with k_shade_ends<0> + list compaction where used) */
 #define VMX_K_TRACE_BOUNCE 3  /* k_trace_w<1>: BVH traversal of the bounce generations     */
-#define VMX_K_SHADE_BOUNCE 4  /* k_shade_ends<1> + list compaction + k_shade<1>               */
+#define VMX_K_SHADE_BOUNCE 4  /* k_shade<1> (with k_shade_ends<1> + list compaction where used) */
 #define VMX_K_TAIL 5          /* k_paths<2>: fused kernel that finishes the last generations */
 #define VMX_K_FUSED 6         /* k_paths<0>: whole small passes in one fused kernel        */
 #define VMX_K_RESOLVE 7       /* k_resolve                                                 */

@@ -306,6 +306,27 @@ def test_two_phase_shading_equals_one_phase(sponza):
         osc.close()
 
 
+def test_frames_do_not_depend_on_the_frames_before_them(sponza):
+    """One scene, frames of different kinds in a row (fixed count / early stop, with and without
+    VMX_SAMPLING_ELIDE_DEAD, a counted frame in between): every frame equals the first one of its kind and reports the
+    same counts.  (Round 3: a fixed-count frame read FrameDev::lead, which only the early-stop branch of the pass loop
+    set — it rendered 16 samples per pixel whenever the stack still held the previous early-stop frame's 17.)"""
+    cam = sponza_cam(640, 360, 64)
+    E = va.VMX_SAMPLING_ELIDE_DEAD
+    seq = [(True, E), (False, E), (False, 0), (True, 0), (False, 0), (True, E), (False, E), (False, E), (True, 0), (False, 0),
+           (True, E), (False, 0), (False, E)]
+    ref, cnt = {}, {}
+    for i, (es, samp) in enumerate(seq):
+        if i == 5:
+            sponza.render(cam, va.make_opts(seed=2, early_stop=True, collect_counters=True, pipeline=4))
+        img, st = sponza.render(cam, va.make_opts(seed=2, early_stop=es, sampling=samp, pipeline=4))
+        key = (st["rays_primary"], st["rays_secondary"], st["samples"], st["passes"])
+        assert np.array_equal(bits(ref.setdefault(es, img)), bits(img)), (i, es, samp)
+        assert cnt.setdefault((es, samp), key) == key, (i, es, samp)
+        if not es:
+            assert st["samples"] == 640 * 360 * 64 and st["samples_discarded"] == 0
+
+
 def test_threads_render_and_introspect_concurrently():
     """The ABI is blocking and a scene serialises its own calls (vmx_scene::mu); different scenes may be driven from
     different host threads at the same time, and vmx_scene_describe / _timings / _bvh may be called while another

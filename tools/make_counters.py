@@ -17,9 +17,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = [  # (vmx_timings name, substring of the demangled kernel name)
-    ("raygen", "k_raygen<0>"), ("trace_camera", "k_trace_w<0,"), ("shade_ends_camera", "k_shade_ends<0"), ("shade_camera", "k_shade<0, false, false, true>"),
-    ("trace_bounce", "k_trace_w<1,"), ("shade_ends_bounce", "k_shade_ends<1"), ("shade_bounce", "k_shade<1, false, false, true>"),
+CLASSES = [  # (vmx_timings name, substring of the demangled kernel name) — the kernels of the default (sorted) frame
+    ("raygen", "k_raygen<0>"), ("trace_camera", "k_trace_w<0, false, true>"), ("shade_camera", "k_shade<0, false, false, 2>"),
+    ("trace_bounce", "k_trace_w<1, false, true>"), ("shade_bounce", "k_shade<1, false, false, 2>"),
     ("tail", "k_paths<false, 2"), ("fused", "k_paths<false, 0"), ("resolve", "k_resolve"),
 ]
 N_SIMD, N_CU, NOMINAL_HZ = 1024, 256, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz max clock

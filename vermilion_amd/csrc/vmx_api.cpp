@@ -221,6 +221,7 @@ M3 rotate_axis(const M3 &m, float angle, float ax, float ay, float az) {
 }
 
 int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
+    std::memset(&fr, 0, sizeof(fr));  // (fields a caller sets later — lead, bounce_bits — start defined: a fixed-count frame reads lead)
     const uint32_t W = cam.image_res[0], H = cam.image_res[1], spp = cam.rays_per_pixel;
     if (W == 0 || H == 0) return fail(VMX_ERR_INVALID, "image resolution must be non-zero");
     if ((uint64_t)W * H > 0x7fffffffull / 8) return fail(VMX_ERR_INVALID, "image too large");
@@ -376,7 +377,10 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.lds_primary = std::min(sc->dev.stack_entries, cap ? cap : (uint32_t)VMX_LDS_PRIMARY);
     tn.lds_bounce = std::min(sc->dev.stack_entries, cap ? cap : 9u);
     // bounce generations with fewer live paths than this finish in one fused launch (measured on the
-    // Sponza stand-in: 512 K -> 16 M = 155.7 -> 152.9 ms fixed spp, 23.6 -> 20.8 ms with early stop)
+    // Sponza stand-in: 512 K -> 16 M = 155.7 -> 152.9 ms fixed spp, 23.6 -> 20.8 ms with early stop; round 3, with the
+    // traversal kernel sorting its rays: 16 M / 8 M / 4 M / 2 M = 86.0 / 85.8 / 85.6 / 85.8 ms, early stop 12.0 / 11.8 /
+    // 12.0 / 11.8 — no difference; under VMX_SAMPLING_ELIDE_DEAD, where the first bounce generation is 16 M rays:
+    // 32.3 / 31.7 / 31.6 / 32.3, so render_impl takes 8 M there)
     tn.tail_threshold = o->reserved[2] ? o->reserved[2] : (16u << 20);
     return tn;
 }
@@ -656,12 +660,14 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     // two-phase shading of the split passes (k_shade_ends, then k_shade on what it queues) unless reserved[0] bit 8 asks
     // for the one-phase form; the counting build keeps the one-phase form (an A/B of the two inside every test that
     // compares a counted with an uncounted call)
-    tn.two_phase = !count && !(opts->reserved[0] & 0x100u);
+    // (r2 = U: hardly a step ends by its draws — only Russian roulette past depth 5 — so there the extra phase is pure
+    // overhead: `corrected` 64-spp bench frame 1.80 s one-phase, 1.92 s two-phase)
+    tn.two_phase = !count && !(opts->reserved[0] & 0x100u) && fr.r2scale == 10.0f;
     // camera rays: the traversal kernel settles the rays whose step ends by its draws (and that no light sphere can
-    // colour) when they finish, and hands the others on as records; reserved[0] bit 9 keeps k_shade_ends for them.
-    // (r2 = U: hardly a step ends by its draws, the records would only add bytes)
-    tn.sorted = tn.two_phase && fr.r2scale == 10.0f && !(opts->reserved[0] & 0x200u);
+    // colour) when they finish, and hands the others on as records; reserved[0] bit 9 keeps k_shade_ends for them
+    tn.sorted = tn.two_phase && !(opts->reserved[0] & 0x200u);
     fr.bounce_bits = tn.sorted ? 1u : 0u;
+    if (fr.elide_dead && !opts->reserved[2]) tn.tail_threshold = 8u << 20;
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
         return VMX_OK;
