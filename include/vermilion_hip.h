@@ -114,8 +114,11 @@ typedef struct vmx_opts {
     uint32_t samples_per_batch; /* fixed-spp mode: samples per pixel in flight per pass; 0 -> auto */
     uint32_t collect_counters;  /* 1: also count inner-node visits / triangle tests
                                    (instrumented kernels, slower; for roofline accounting) */
-    uint32_t reserved[7];  /* 0 unless tuning: [0] pipeline form, [1] max paths per pass, [2] tail threshold,
-                              [3] refill_min, [4] shade_min, [5] leaf_min, [6] LDS stack levels — all forms and
+    uint32_t reserved[7];  /* 0 unless tuning: [0] pipeline form (bits 0-7: 0 default routing, 1 fused kernel for every
+                              pass, 4 split wavefront for every pass; bit 8: plain one-phase shading; bit 9: two-phase
+                              shading through k_shade_ends instead of rays sorted by the traversal kernel),
+                              [1] max paths per pass, [2] tail threshold, [3] refill_min, [4] shade_min,
+                              [5] bounce reordering key (A/B library only), [6] LDS stack levels — all forms and
                               settings produce the same frame (see vmx_api.cpp: render_impl, make_tuning) */
 } vmx_opts;
 

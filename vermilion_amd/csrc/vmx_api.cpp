@@ -667,7 +667,15 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     // colour) when they finish, and hands the others on as records; reserved[0] bit 9 keeps k_shade_ends for them
     tn.sorted = tn.two_phase && !(opts->reserved[0] & 0x200u);
     fr.bounce_bits = tn.sorted ? 1u : 0u;
-    if (fr.elide_dead && !opts->reserved[2]) tn.tail_threshold = 8u << 20;
+    if (!opts->reserved[2]) {
+        // measured (tools/elide_probe.py, tools/shard_probe.py): the whole frame on one GPU does not care between 2 M and
+        // 16 M (86.0 / 85.8 / 85.6 / 85.8 ms at 16 / 8 / 4 / 2 M); a rank of a sharded frame does — its first bounce
+        // generation (9 M rays on one of 8 ranks) runs 0.5 ms faster split than fused (13.8 -> 13.3 ms) — and so does
+        // VMX_SAMPLING_ELIDE_DEAD, whose first generation is 16 M rays (32.3 -> 31.7 ms)
+        uint32_t thr = fr.elide_dead ? (8u << 20) : (16u << 20);
+        thr /= std::min(fr.world, 4u);
+        tn.tail_threshold = std::max(thr, 2u << 20);
+    }
     if (npix == 0) {
         if (stats) std::memset(stats, 0, sizeof(*stats));
         return VMX_OK;

@@ -2033,8 +2033,8 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
 // spot when the wave refills.  A ray whose Radiance step is the path's last one by the path's own draws (the bits that
 // came with the ray) and that cannot meet a light sphere needs nothing more: it is counted here and forgotten.  The
 // others get a 32-byte record (direction, flag word | t, leaf slot, position) appended to a dense list — the wave
-// reserves 256 entries at a time with one atomic and pads what it leaves unused with position = ~0 — which k_shade
-// reads front to back.
+// reserves 256 entries at a time with one atomic, fills them to the last one, and pads the tail of its last chunk with
+// position = ~0 when it ends — which k_shade reads front to back.
 constexpr uint32_t kOutChunk = 256;
 template <int SRC, bool LIVE = false, bool SORT = false>
 __global__ void __launch_bounds__(256, VMX_TRACE_WAVES_PER_SIMD) __attribute__((amdgpu_num_sgpr(VMX_TRACE_SGPRS)))
@@ -2092,19 +2092,24 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         float4 *__restrict__ rec = (float4 *)wk.out_rec;
         if (n != 0) {
             constexpr uint32_t kRec = SRC == 0 ? 2 : 1;  // float4s per entry; the last one holds (t, leaf slot, position, -)
-            if (n > out_hi - out_lo) {  // pad what is left of the chunk, take a new one
-                if (lane < out_hi - out_lo) rec[(size_t)(out_lo + lane) * kRec + (kRec - 1)] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
+            // the entries fill the wave's chunk to its end and go on in a new one: nothing is left unused but the tail of
+            // the wave's last chunk (padded at the end), so the list never holds more than rays + 255 per wave
+            const uint32_t rem = out_hi - out_lo, rank = (uint32_t)__popcll(m & lt_mask);
+            uint32_t at = out_lo + rank;
+            if (n > rem) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(wk.out_count, kOutChunk);
-                out_lo = __builtin_amdgcn_readfirstlane(base);
-                out_hi = out_lo + kOutChunk;
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (rank >= rem) at = base + (rank - rem);
+                out_lo = base + (n - rem);
+                out_hi = base + kOutChunk;
+            } else {
+                out_lo += n;
             }
             if (todo) {
-                const size_t at = (size_t)(out_lo + (uint32_t)__popcll(m & lt_mask)) * kRec;
-                if (SRC == 0) rec[at] = make_float4(dx, dy, dz, __uint_as_float(rflags & 7u));  // (bounce paths: ray and stream are in state[pid])
-                rec[at + (kRec - 1)] = make_float4(best, __int_as_float(slot), __uint_as_float(pid), 0.f);
+                if (SRC == 0) rec[(size_t)at * kRec] = make_float4(dx, dy, dz, __uint_as_float(rflags & 7u));  // (bounce paths: ray and stream are in state[pid])
+                rec[(size_t)at * kRec + (kRec - 1)] = make_float4(best, __int_as_float(slot), __uint_as_float(pid), 0.f);
             }
-            out_lo += n;
         }
         rflags &= 0x7FFFFFFFu;
     };

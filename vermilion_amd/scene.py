@@ -39,7 +39,7 @@ def make_opts(seed=1, early_stop=True, sampling=L.VMX_SAMPLING_PARITY, rank=0, w
     o.rank, o.world, o.stripe_rows = int(rank), int(world), int(stripe_rows)
     o.samples_per_batch = int(samples_per_batch)
     o.collect_counters = 1 if collect_counters else 0
-    o.reserved[0] = int(pipeline)      # 0 default routing, 1 fused kernel for every pass, 4 split wavefront for every pass; 2/3 first-generation kernels (A/B library only)
+    o.reserved[0] = int(pipeline)      # 0 default routing, 1 fused kernel for every pass, 4 split wavefront for every pass; 2/3 first-generation kernels (A/B library only); | 0x100 one-phase shading, | 0x200 two-phase shading (k_shade_ends) instead of sorted rays
     o.reserved[1] = int(max_paths)     # paths in flight per pass (0 -> 16M)
     o.reserved[2] = int(tail_threshold)
     o.reserved[3] = int(refill_min)    # k_paths: refill when this many lanes idle (0 -> 16)
