@@ -127,9 +127,9 @@ def main():
     local = torch.empty((rows, W, 5), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step(early_stop=False, counters=False, sampling=va.VMX_SAMPLING_PARITY):
+    def step(early_stop=False, counters=False, sampling=va.VMX_SAMPLING_PARITY, pipeline=0):
         opts = va.make_opts(seed=args.seed, early_stop=early_stop, sampling=sampling, rank=rank,
-                            world=world, stripe_rows=stripe, collect_counters=counters, reorder=args.reorder)
+                            world=world, stripe_rows=stripe, collect_counters=counters, reorder=args.reorder, pipeline=pipeline)
         st = sc.render_device(cam, opts, local.data_ptr(), stream)
         st["kernels"] = sc.timings()  # per-kernel hipEvent durations of this frame (on the render stream)
         src = local if args.backend == "nccl" or world == 1 else local.cpu()
@@ -176,6 +176,27 @@ def main():
         step(early_stop=True)
         es_k = max(1, min(args.steps, 3))
         es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
+
+    # The headline frame settles the Radiance steps that end by the path's own draws without the part of RayCast nobody
+    # reads for them (the hit's normal and uv, the wall spheres: DESIGN.md 5.1) — every ray is still traced to its nearest
+    # triangle and counted.  For comparison, the same frame with every step shaded in full (vmx_opts.reserved[0] bit 8):
+    full_info = None
+    if not args.no_extras:
+        _, g0 = step()
+        g0 = g0.clone() if g0 is not None else None
+        _, g1 = step(pipeline=0x100)
+        fs_k = max(1, min(args.steps, 3))
+        fs_dt, fs_rays, fs_stats = timed(fs_k, pipeline=0x100)
+        full_info = {
+            "what": "the headline frame with every Radiance step shaded in full (one-phase k_shade over all paths, hit records "
+                    "for all rays; vmx_opts.reserved[0] bit 8) instead of the traversal kernels settling the steps that end by "
+                    "the path's own draws",
+            "frame_bit_identical_to_headline": bool(torch.equal(g0.view(torch.int32), g1.view(torch.int32))) if rank == 0 else None,
+            "ms_per_frame": round(fs_dt / fs_k * 1e3, 3), "Mrays_per_s": round(fs_rays / fs_dt / 1e6, 2),
+            "rays_per_frame": int(fs_rays / fs_k),
+            "kernel_ms": {k: round(sum(x["kernels"][k]["ms"] for x in fs_stats) / fs_k, 3)
+                          for k in fs_stats[0]["kernels"] if fs_stats[0]["kernels"][k]["launches"]},
+        }
 
     # VMX_SAMPLING_ELIDE_DEAD: the same frames, bit for bit, without the rays whose step cannot change the path's colour
     # (78 % of them under the reference's r2 = 10 U).  Wall-clock per frame is the second half of BASELINE.json's metric;
@@ -431,6 +452,9 @@ def main():
                 "workload": f"{args.scene} ({desc['ntris']} tris, procedural Sponza stand-in) {W}x{H} {spp}spp, "
                             "reference sampling (r2=10U), fixed spp (early stop off), reference sphere table",
                 "rays_per_frame": int(rays / args.steps),
+                "ray": "every ray the reference traces, traced to its nearest triangle (BVH::getIntersection) and counted; the "
+                       "rest of RayCast (normal, uv, wall spheres) is evaluated for the rays whose Radiance step reads it — "
+                       "DESIGN.md 5.1; full_shading_frame gives the frame with it evaluated for all",
                 "parallelism": f"stripes{stripe}x{world}" if world > 1 else "single",
                 "bvh": {"nodes": desc["n_nodes"], "max_depth": desc["max_depth"], "leaf_size": desc["leaf_size"]},
             },
@@ -461,6 +485,8 @@ def main():
         if q_info:
             out["quality_bvh"] = q_info
             out["quality_bvh_gpu_built"] = p_info
+        if full_info:
+            out["full_shading_frame"] = full_info
         if el_info:
             out["elided_frame"] = el_info
         if corr_info:
