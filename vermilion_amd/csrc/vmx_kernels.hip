@@ -749,8 +749,8 @@ __device__ __forceinline__ bool path_shade_end(Path &P, const CastResult &c, Ste
 // No light sphere can colour it iff sphereIntersect is 0 for every emitting sphere — the reference's own arithmetic with
 // nothing nearer yet (limit = infinity).  Then accumColour after the step equals accumColour before it bit for bit
 // (x + t * 0 == x for finite t), so the ray need not be traced: with the reference's r2 = 10 U that is 78 % of all rays.
-// (Nothing is ever elided under VMX_SAMPLING_CORRECTED: r2 = U never exceeds 1.)
-// The same facts as three bits — what the kernels pass along with a ray:
+// (Under VMX_SAMPLING_CORRECTED r2 = U never exceeds 1: only Russian roulette, past depth 5, ever ends a path by its draws.)
+// The same facts as three bits — what the kernels pass along with a ray, step_is_dead being "bits == 3":
 //   bit 0  the step is the path's last one if its hit has a material   (Russian roulette, or the draws of :98 / :156)
 //   bit 1  ... if its hit has none                                      (Russian roulette, or the draw of :170)
 //   bit 2  some light sphere passes sphereIntersect > 0 for the ray with nothing nearer yet: hitColour may be non-zero
@@ -778,11 +778,9 @@ __device__ __forceinline__ uint32_t step_bits(const SceneDev &sc, float r2scale,
     }
     return (ends_mat ? 1u : 0u) | (ends_nomat ? 2u : 0u) | (light ? 4u : 0u);
 }
-template <bool TEX, bool LDS_GEOM>
+template <bool TEX>
 __device__ __forceinline__ bool step_is_dead(const SceneDev &sc, float r2scale, Rng rng, uint32_t depth, float ox, float oy,
-                                             float oz, float dx, float dy, float dz, float tr, float tg, float tb,
-                                             const float4 *geom = nullptr) {
-    (void)geom;
+                                             float oz, float dx, float dy, float dz, float tr, float tg, float tb) {
     return step_bits<TEX>(sc, r2scale, rng, depth, ox, oy, oz, dx, dy, dz, tr, tg, tb) == 3u;
 }
 
@@ -798,7 +796,7 @@ __device__ __forceinline__ bool path_shade(const SceneDev &sc, SampCfg cfg, Path
         shade_trig(m, cfg.libm_double, cs, sn);
         alive = path_shade_end(P, c, fl, m, cs, sn);
     }
-    if (cfg.elide && alive && step_is_dead<TEX, LDS_GEOM>(sc, cfg.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb, geom))
+    if (cfg.elide && alive && step_is_dead<TEX>(sc, cfg.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb))
         alive = false, fl.continues = false;
     return alive;
 }
@@ -1266,8 +1264,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, float4 *__restri
                                     P.tr = P.tg = P.tb = 1.f;  // :30
                                     P.depth = 0;
                                     P.dest = path_id(wk, j, s_idx);
-                                    if (fr.elide_dead && step_is_dead<false, true>(sc, fr.r2scale, P.rng, 0, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz,
-                                                                                   1.f, 1.f, 1.f, s_geom)) {
+                                    if (fr.elide_dead && step_is_dead<false>(sc, fr.r2scale, P.rng, 0, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, 1.f, 1.f, 1.f)) {
                                         rad[P.dest] = make_float4(0.f, 0.f, 0.f, -100.f);  // untraced: its radiance is zero
                                         valid = false;
                                     }
@@ -1459,7 +1456,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
                 if (k < fr.kmax) {
                     Rng rng;
                     primary_ray(fr, global_pixel(fr, lp), k, rng, dx, dy, dz);
-                    if (LIVE) live = !step_is_dead<false, false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+                    if (LIVE) live = !step_is_dead<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
                     else depth = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
                 }
                 if (!LIVE) ((float4 *)pa.rayA)[pid0 + lane] = make_float4(dx, dy, dz, __uint_as_float(depth));
@@ -1485,7 +1482,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
         if (s_idx < wk.n_active && primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
-            if (LIVE) live = !step_is_dead<false, false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+            if (LIVE) live = !step_is_dead<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
             else depth = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
         }
         // camera rays share the origin (FrameDev): one 16-byte record in rayA — direction, and a word that is ~0 for a
@@ -2604,7 +2601,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             alive = path_shade_end(P, c, fl, mid, cs, sn);
         }
         if (ELIDE && alive &&
-            step_is_dead<TEX, true>(sc, fr.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb, s_geom))
+            step_is_dead<TEX>(sc, fr.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb))
             alive = false, fl.continues = false;  // VMX_SAMPLING_ELIDE_DEAD: the next ray cannot change the path's colour
         if (alive) {
             uint32_t bits = 0;
