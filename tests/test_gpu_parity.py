@@ -493,6 +493,34 @@ def checker_texture(h, w, c, seed):
     return t if c > 1 else t[:, :, 0]
 
 
+def test_texture_with_infinities_and_zeros_nan_pixels_stay_nan():
+    """A texture may hold anything: an infinite throughput times a black hit is NaN (pathtracer.cpp:43), the pixel's mean
+    is NaN, and std::max(std::min(x, 1.f), 0.f) (:318-320) leaves a NaN a NaN — (b < a) ? b : a, not fminf / fmaxf.
+    (tools/fuzz_parity.py's random textures found the kernels returning 1 there, round 3.)  Also the steps whose
+    colour product would be NaN are never settled early (step_bits: non-finite throughput)."""
+    pos, nrm, uv = scenes.bunny70k()
+    tex = np.array([[np.inf, 0.5, 0.0, -1.5], [2.0, -np.inf, 1.0, 0.25]], np.float32).reshape(2, 4, 1).repeat(3, axis=2)
+    tex[0, 1, 1] = np.inf
+    lights = va.spheres_array([
+        dict(centre=(0, 700, 300), radius=220, colour=(1.5, 1.2, 0.9), emit=True),
+        dict(centre=(0, 300, 0), radius=5000, colour=(0.2, 0.1, 0.3), emit=True, normal_sign=-1)])
+    p = Pair(pos, nrm, uv * np.float32(5.3), spheres=lights)
+    p.gpu.bind_texture(tex)
+    p.cpu.bind_texture(tex)
+    c = scenes.bunny_camera()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 128, 96, 64, back_size=(3.6, 2.7))
+    for sampling in (0, 1):
+        for es in (False, True):
+            ref, rst = p.cpu.render(cam, va.make_opts(seed=13, sampling=sampling, early_stop=es))
+            assert np.isnan(ref[:, :, :3]).any()  # the case is there
+            for kw in ({}, {"pipeline": 1}, {"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1}, {"pipeline": 4 | 0x100}, {"pipeline": 4 | 0x200}):
+                for flag in (0, va.VMX_SAMPLING_ELIDE_DEAD):
+                    img, st = p.gpu.render(cam, va.make_opts(seed=13, sampling=sampling | flag, early_stop=es, **kw))
+                    assert np.array_equal(bits(img), bits(ref)), (sampling, es, kw, flag)
+                    assert st["samples"] == rst["samples"]
+    p.close()
+
+
 @pytest.mark.parametrize("channels,size", [(1, (5, 7)), (3, (64, 32)), (4, (2, 2)), (2, (9, 1))])
 def test_textured_paths_bit_exact_f2(channels, size):
     """§8 f-2: boundTextures[0] sampled at the BVH hit's uv (wrap + nearest) modulates the throughput"""

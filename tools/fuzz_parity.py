@@ -42,15 +42,28 @@ for case in range(cases):
     kw = [{"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1}, {"pipeline": 4, "lds_entries": int(rng.choice([1, 3, 6, 40]))}, {},
           {"pipeline": 4 | 0x200, "tail_threshold": 1}, {"pipeline": 4 | 0x100, "tail_threshold": 1}][rng.integers(0, 6)]
     try:
+        # a random texture in one case of four: 1-4 channels, values below 0 and above 1, now and then an infinity or a
+        # zero (throughput 0 or inf: the steps whose colour product would be NaN must be shaded in full)
+        tex = None
+        if rng.random() < 0.25:
+            ch = int(rng.integers(1, 5))
+            tex = rng.uniform(-0.5, 2.0, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), ch)).astype(np.float32)
+            tex[rng.random(tex.shape) < 0.05] = np.float32(rng.choice([0.0, np.inf, -np.inf]))
+            if ch == 1: tex = tex[:, :, 0]
         with va.Scene(pos, nrm, uv, spheres=spheres, leaf_size=leaf, builder=builder) as g:
             osc = O.OracleScene(pos, nrm, uv, spheres=spheres, leaf_size=leaf, tree=g.bvh() if builder else None)
+            if tex is not None:
+                g.bind_texture(tex)
+                osc.bind_texture(tex)
             seed = int(rng.integers(1, 1 << 30))
             opts = va.make_opts(seed=seed, early_stop=es, sampling=sampling, **kw)
             img, st = g.render(cam, opts)
             ref, rst = osc.render(cam, opts)
             same = np.array_equal(bits(img), bits(ref)) and st["samples"] == rst["samples"]
+            why = "" if same else f" [default form: {int((bits(img) != bits(ref)).any(axis=2).sum())} pixels differ]"
             # VMX_SAMPLING_ELIDE_DEAD: the same frame from fewer rays
             img2, st2 = g.render(cam, va.make_opts(seed=seed, early_stop=es, sampling=sampling | va.VMX_SAMPLING_ELIDE_DEAD, **kw))
+            if not np.array_equal(bits(img2), bits(ref)): why += f" [with elision: {int((bits(img2) != bits(ref)).any(axis=2).sum())} pixels differ]"
             same = same and np.array_equal(bits(img2), bits(ref)) and st2["samples"] == rst["samples"]
             same = same and st2["rays_primary"] + st2["rays_secondary"] <= st["rays_primary"] + st["rays_secondary"]
             osc.close()
@@ -59,6 +72,6 @@ for case in range(cases):
         continue
     bad += not same
     print(f"case {case:3d}: {kind:10s} n={n:5d} leaf={leaf:2d} builder={builder} spp={spp:3d} sampling={sampling:#x} es={int(es)} {kw} -> "
-          f"{'ok' if same else 'MISMATCH'} ({st['rays_primary'] + st['rays_secondary']} rays, {st2['rays_primary'] + st2['rays_secondary']} with elision{', spheres' if spheres is not None else ''})", flush=True)
+          f"{'ok' if same else 'MISMATCH'} ({st['rays_primary'] + st['rays_secondary']} rays, {st2['rays_primary'] + st2['rays_secondary']} with elision{', spheres' if spheres is not None else ''}{', textured' if tex is not None else ''}){why}", flush=True)
 print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

@@ -2905,9 +2905,14 @@ __global__ void k_resolve(FrameDev fr, const unsigned int *__restrict__ active, 
         if (next >= fr.kmax) {
             const float fn = (float)n;  // accum / nTotalSamples (uint -> float)
             float *o5 = out + (size_t)lp * 5;
-            o5[0] = fmaxf(fminf(acc.x / fn, 1.f), 0.f);
-            o5[1] = fmaxf(fminf(acc.y / fn, 1.f), 0.f);
-            o5[2] = fmaxf(fminf(acc.z / fn, 1.f), 0.f);
+            // std::max(std::min(x, 1.f), 0.f) (pathtracer.cpp:318-320): std::min(a, b) is (b < a) ? b : a, so a NaN mean —
+            // an infinite throughput times a black hit, possible with a texture that holds an infinity — stays NaN
+            // (fminf / fmaxf would return the other operand: found by tools/fuzz_parity.py's random textures, round 3)
+            const float mx = acc.x / fn, my = acc.y / fn, mz = acc.z / fn;
+            const float cx = 1.f < mx ? 1.f : mx, cy = 1.f < my ? 1.f : my, cz = 1.f < mz ? 1.f : mz;
+            o5[0] = cx < 0.f ? 0.f : cx;
+            o5[1] = cy < 0.f ? 0.f : cy;
+            o5[2] = cz < 0.f ? 0.f : cz;
             o5[3] = 1.f;
             o5[4] = fn;
             done = 1;
