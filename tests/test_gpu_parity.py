@@ -518,6 +518,20 @@ def test_texture_with_infinities_and_zeros_nan_pixels_stay_nan():
                     img, st = p.gpu.render(cam, va.make_opts(seed=13, sampling=sampling | flag, early_stop=es, **kw))
                     assert np.array_equal(bits(img), bits(ref)), (sampling, es, kw, flag)
                     assert st["samples"] == rst["samples"]
+    # Radiance's fourth component: accumColour += accumRadiance * vec4(hitColour, 0.f) (:43) turns it into a NaN once the
+    # product of the samples' fourth components is not finite (one channel: the texel itself; four channels: its alpha)
+    o, d = O.primary_rays(cam, va.make_opts(seed=13), 2)
+    for t in (tex[:, :, 0].copy(), np.concatenate([np.ones((2, 4, 3), np.float32), tex[:, :, :1]], axis=2)):
+        q = Pair(pos, nrm, uv * np.float32(5.3), spheres=lights)
+        q.gpu.bind_texture(t)
+        q.cpu.bind_texture(t)
+        for sampling in (0, 1):
+            rrad, _ = q.cpu.radiance(o, d, va.make_opts(seed=13, sampling=sampling))
+            assert np.isnan(rrad[:, 3]).any() and not np.isnan(rrad[:, 3]).all()
+            for kw in ({}, {"pipeline": 4, "tail_threshold": 1}):
+                rad, _ = q.gpu.radiance(o, d, va.make_opts(seed=13, sampling=sampling, **kw))
+                assert np.all(same_f32(rad, rrad)), (t.shape, sampling, kw)
+        q.close()
     p.close()
 
 

@@ -539,7 +539,8 @@ __device__ __forceinline__ void ray_cast(const SceneDev &sc, float ox, float oy,
 // ---------------------------------------------------------------------------
 struct Path {
     float ox, oy, oz, dx, dy, dz;
-    float tr, tg, tb;      // accumRadiance (rgb); only maintained by the textured kernels
+    float tr, tg, tb, tw;  // accumRadiance; only maintained by the textured kernels (w: the product of the samples' fourth
+                           // components — it only ever reaches accumColour.w as tw * 0, i.e. as a NaN when it is not finite)
     float ar, ag, ab, aw;  // accumColour
     uint32_t depth, dest;
     Rng rng;
@@ -659,6 +660,7 @@ __device__ __forceinline__ int path_shade_begin(const SceneDev &sc, float r2scal
         P.ar = P.ar + P.tr * c.cr;
         P.ag = P.ag + P.tg * c.cg;
         P.ab = P.ab + P.tb * c.cb;
+        P.aw = P.aw + P.tw * 0.f;  // accumRadiance * vec4(hitColour, 0.f): NaN once the fourth component is not finite
     } else {
         // untextured: accumRadiance stays (1,1,1,1) — the only factor ever applied to it is the white
         // albedo (:75-79,153) — so the product is exactly hitColour
@@ -695,6 +697,7 @@ __device__ __forceinline__ int path_shade_begin(const SceneDev &sc, float r2scal
             P.tr = P.tr * tx.x;
             P.tg = P.tg * tx.y;
             P.tb = P.tb * tx.z;
+            P.tw = P.tw * tx.w;
         }
         const float r1 = (float)(6.283185307179586 * rng_u01(P.rng));
         const float r2 = (float)((double)r2scale * rng_u01(P.rng));
@@ -905,7 +908,7 @@ __device__ __forceinline__ void path_load_arrays(const PathArrays &pa, uint32_t 
     P.ar = acc.x, P.ag = acc.y, P.ab = acc.z, P.aw = acc.w;
     if (TEX) {
         const float4 th = ((const float4 *)pa.thr)[pid];
-        P.tr = th.x, P.tg = th.y, P.tb = th.z;
+        P.tr = th.x, P.tg = th.y, P.tb = th.z, P.tw = th.w;
     }
     P.dest = pid;
 }
@@ -1261,7 +1264,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, float4 *__restri
                                     P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz;
                                                         P.ar = P.ag = P.ab = 0.f;
                                     P.aw = -100.f;  // pathtracer.cpp:29
-                                    P.tr = P.tg = P.tb = 1.f;  // :30
+                                    P.tr = P.tg = P.tb = P.tw = 1.f;  // :30
                                     P.depth = 0;
                                     P.dest = path_id(wk, j, s_idx);
                                     if (fr.elide_dead && step_is_dead<false>(sc, fr.r2scale, P.rng, 0, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, 1.f, 1.f, 1.f)) {
@@ -2552,7 +2555,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
                 (void)rng_next(P.rng);
                 P.ar = P.ag = P.ab = 0.f;
                 P.aw = -100.f;  // pathtracer.cpp:29
-                P.tr = P.tg = P.tb = 1.f;  // :30
+                P.tr = P.tg = P.tb = P.tw = 1.f;  // :30
             }
         } else {
             uint32_t sub = item % kSubQueues, chunk = item / kSubQueues;
@@ -2608,7 +2611,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             if (fr.bounce_bits) bits = step_bits<TEX>(sc, fr.r2scale, P.rng, P.depth, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, P.tr, P.tg, P.tb);
             ray_store(pa, pid, P, bits);
             rng_store(pa, pid, P.rng);
-            if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, 1.f);
+            if (TEX) ((float4 *)pa.thr)[pid] = make_float4(P.tr, P.tg, P.tb, P.tw);
         }
         if (SRC == 0 && pa.rad_mask) {
             // camera paths: most end at their first hit with accumColour.rgb == 0 (no light sphere hit): nothing to store
