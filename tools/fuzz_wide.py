@@ -4,7 +4,8 @@ does not vary.  Per case, on a random triangle soup with a random sphere table a
               and samples-per-batch (many passes), a random rank of a random world with random stripes against the rows
               of the oracle's whole frame, every pipeline form, with and without VMX_SAMPLING_ELIDE_DEAD
   radiance    explicit rays incl. axis-parallel, zero, infinite and NaN directions and origins
-  raycast     the same rays through vmx_raycast
+  raycast     the same rays through vmx_raycast, vmx_trace; vmx_primary_ids of a random sample index
+  multi       the frame through vmx_multi_* with 2-3 replicas (one case in three)
   bruteforce  BruteForceTracer frames with both readings of abs()
 Everything must be bit-identical to the oracle.   python tools/fuzz_wide.py [cases] [seed]"""
 import os, sys, time
@@ -100,6 +101,16 @@ for case in range(cases):
                     hit = osc.raycast(ro[i0:i0 + 1], rd[i0:i0 + 1])
                     msgs.append(f"radiance {kw}: {len(badp)} paths, e.g. {badp[:6].tolist()}: o={ro[i0].tolist()} d={rd[i0].tolist()} gpu={rad[i0].tolist()} "
                                 f"oracle={rrad[i0].tolist()} first hit uv={hit['uv'][0].tolist()} tri={int(hit['tri_id'][0])}")
+            tri, tt = g.trace(ro, rd)
+            rtri, rtt = osc.trace(ro, rd)
+            if not (np.array_equal(tri, rtri) and np.all(same_f32(tt, rtt))):
+                msgs.append(f"trace: {int((tri != rtri).sum())} ids, {int((~same_f32(tt, rtt)).sum())} distances")
+            kk = int(rng.integers(0, 4 * (spp // 4)))
+            ptri, pt = g.primary_ids(cam, va.make_opts(seed=seed), kk)
+            po, pd = O.primary_rays(cam, va.make_opts(seed=seed), kk)
+            qtri, qt = osc.trace(po, pd)
+            if not (np.array_equal(ptri, qtri) and np.all(same_f32(pt, qt))):
+                msgs.append("primary_ids")
             a, b = g.raycast(ro, rd), osc.raycast(ro, rd)
             for f in a.dtype.names:
                 if f == "pad":
@@ -107,6 +118,16 @@ for case in range(cases):
                 same = same_f32(a[f], b[f]) if a[f].dtype == np.float32 else (a[f] == b[f])
                 if not np.all(same):
                     msgs.append(f"raycast.{f}: {int((~same).sum())} (first at ray {int(np.argwhere(~same)[0][0])})")
+            # the one-process multi-device path (replicas on this GPU), whole frame
+            if rng.random() < 0.3:
+                mw = int(rng.choice([2, 3]))
+                with va.MultiScene(pos, nrm, uv, devices=[0] * mw, spheres=spheres, leaf_size=leaf) as m:
+                    for t in texs:
+                        m.bind_texture(t)
+                    for flag in (0, va.VMX_SAMPLING_ELIDE_DEAD):
+                        mi, _ = m.render(cam, va.make_opts(seed=seed, early_stop=es, sampling=sampling | flag, stripe_rows=stripe))
+                        if not np.array_equal(bits(mi), bits(ref)):
+                            msgs.append(f"multi x{mw} flag {flag:#x}: {int((bits(mi) != bits(ref)).any(axis=2).sum())} pixels")
             # BruteForceTracer
             bcam = va.make_camera(tuple(float(v) for v in cpos), tuple(float(v) for v in rot), min(W, 48), min(H, 32), min(spp, 64))
             for flags in (0, va._lib.VMX_BF_ABS_INT):
