@@ -51,6 +51,21 @@ def test_single_gpu_line_carries_roofline_cpu_baseline_and_the_extra_frames():
     cf = d["corrected_frame"]
     assert cf["spp"] == 8 and cf["rays_per_sample"] > 5 and cf["Mrays_per_s"] > 0
     assert d["bruteforce_frame"]["ms_per_frame"] > 0 and d["quality_bvh"]["inner_visits_per_ray"] > 0
+    # the two frames that say what the headline's rays are and what leaving the unread ones out gains
+    fs = d["full_shading_frame"]
+    assert fs["frame_bit_identical_to_headline"] is True and fs["rays_per_frame"] == d["config"]["rays_per_frame"] and fs["ms_per_frame"] > 0
+    el = d["elided_frame"]
+    assert el["frames_bit_identical_to_default"] is True
+    assert 0 < el["fixed_count"]["rays_per_frame"] < 0.5 * d["config"]["rays_per_frame"]
+    assert 0 < el["early_stop"]["rays_per_frame"] < rf["rays_per_frame"] and "ray" in d["config"]
+
+
+def test_two_ranks_with_the_extra_frames():
+    """... and once with the extra frames (early stop, full shading, elision) through the sharded path"""
+    d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", "29534", "bench.py", "--gpus", "2", "--backend", "gloo", "--device", "0", "--no-cpu-baseline"] + SMALL)
+    check_common(d, 2)
+    assert d["elided_frame"]["frames_bit_identical_to_default"] is True and d["full_shading_frame"]["frame_bit_identical_to_headline"] is True
 
 
 def test_multi_device_form_in_one_process():
