@@ -8,9 +8,12 @@
 // Kernels
 //   k_trace        BVH::getIntersection for explicit rays          (bvh.cpp:47-145)
 //   k_raycast      MeshEngine::RayCast for explicit rays           (meshEngine.cpp:239-509)
-//   k_raygen       camera rays of a pass                           (pathtracer.cpp:251-280)
-//   k_trace_w      persistent BVH traversal of camera / bounce rays (bvh.cpp:47-145); k_trace_q: counting form
-//   k_shade        RayCast tail + one Radiance step, id compaction  (meshEngine.cpp:365-508, pathtracer.cpp:36-196)
+//   k_raygen       camera rays of a pass, each with the step_bits of its first Radiance step (pathtracer.cpp:251-280);
+//                  <1> + k_raygen_live: only the live ones (VMX_SAMPLING_ELIDE_DEAD, with path_compact.hip)
+//   k_trace_w      persistent BVH traversal of camera / bounce rays (bvh.cpp:47-145); <.., SORT>: settles the finished rays
+//                  whose step ends by its draws, hands the others on as records; k_trace_q: counting form
+//   k_shade        RayCast tail + one Radiance step, id compaction  (meshEngine.cpp:365-508, pathtracer.cpp:36-196);
+//                  k_shade_ends: the two-phase form's first phase
 //   k_paths        traversal + shading fused, paths kept to their end (small passes, the tail of a pass)
 //   k_resolve      per-pixel accumulation, early stop, pixel write (pathtracer.cpp:282-324)
 //   k_bruteforce*  BruteForceTracer::Render                        (integrators.cpp:9-186)
