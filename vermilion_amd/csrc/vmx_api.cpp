@@ -773,8 +773,9 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         ws.full_words = words, ws.full_tmp_bytes = tmp;
     }
     if (split_any && tn.sorted) {
-        // every path of a pass may need a record; a wave pads at most one chunk of 256 (16 K waves at most)
-        if (ws.out_rec.ensure(((size_t)n_pad_max * smax + (4u << 20)) * 32) || ws.out_count.ensure(32))
+        // every path of a pass may need a record; each wave of the launch leaves at most the tail of one chunk of 256 unused
+        const size_t waves = (size_t)sc->num_cus * (size_t)std::max(tb, tbb) * (kPathsBlock / 64);
+        if (ws.out_rec.ensure(((size_t)n_pad_max * smax + waves * 256 + 1024) * 32) || ws.out_count.ensure(32))
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the sorted camera-ray records");
     }
     size_t live_tmp_bytes = 0;
