@@ -3,7 +3,14 @@
 
 One "step" = one full frame of the Sponza stand-in (256,152 triangles) at
 1920x1080, 256 spp, rendered by the HIP path tracer (PathTracer::Render
-equivalent), inputs resident in HBM before the timed region.  With N > 1 the
+equivalent), inputs resident in HBM before the timed region.  The timed frame
+is the one in which EVERY counted ray is a full MeshEngine::RayCast — BVH query,
+the whole sphere table, normal, uv ("a ray = one nearest-hit
+query (BVH + sphere table)"; vmx_opts.reserved[0] bit 8).  The library's
+default form of the same frame (the traversal kernels settle the rays whose
+Radiance step ends by the path's own draws) and the VMX_SAMPLING_ELIDE_DEAD form
+are bit-identical frames that take less time: they are reported beside it
+(`frame_ms`), never as `value`.  With N > 1 the
 frame is sharded into interleaved 16-row (4-row beyond 4 ranks) stripes (one process per GPU), the
 packed stripes are gathered to rank 0 over RCCL and de-interleaved there; the
 gather and assembly are inside the timed step.
@@ -33,6 +40,9 @@ from vermilion_amd import dist as vdist  # noqa: E402
 from vermilion_amd import scenes  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# vmx_opts.reserved[0] bit 8: every Radiance step shaded in full by k_shade (one phase over all paths, a hit record per
+# ray) — every counted ray gets the whole of MeshEngine::RayCast (meshEngine.cpp:239-509), which is SURVEY 8(d)'s ray
+HEADLINE_FORM = 0x100
 # VALU issue roof: 256 CUs x 4 SIMD-32, a wave64 VALU instruction occupies its SIMD for 2 cycles, 2.4 GHz max clock
 # (MI355X_MICROARCH.md "Wave scheduling", "Per-instruction cycle constants") -> wave-level instructions per second
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
@@ -46,12 +56,10 @@ VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2
 A_INNER = {"trace_camera": 20, "trace_bounce": 44}
 A_TRI = {"trace_camera": 36, "trace_bounce": 53}
 KERNEL_TEXT = {
-    "trace_camera": "k_trace_w<0, SORT> (persistent BVH traversal of the camera rays; settles the rays whose step ends by its draws, "
-                    "hands the others on as records)",
-    "trace_bounce": "k_trace_w<1, SORT> (persistent BVH traversal of a bounce generation, quad-cooperative record fetch; sorts its "
-                    "finished rays like the camera kernel)",
-    "shade_camera": "k_shade<0> on the records the camera kernel handed on (RayCast tail + Radiance step)",
-    "shade_bounce": "k_shade<1> on the records the bounce kernel handed on", "tail": "k_paths<2> (fused tail of the last bounce generations)",
+    "trace_camera": "k_trace_w<0> (persistent BVH traversal of the camera rays, one hit record per ray)",
+    "trace_bounce": "k_trace_w<1> (persistent BVH traversal of a bounce generation, quad-cooperative record fetch)",
+    "shade_camera": "k_shade<0> over every camera path (rest of RayCast: sphere table, normal, uv + one Radiance step)",
+    "shade_bounce": "k_shade<1> over every path of a bounce generation", "tail": "k_paths<2> (fused tail of the last bounce generations)",
     "raygen": "k_raygen", "resolve": "k_resolve", "fused": "k_paths<0>",
 }
 
@@ -88,6 +96,9 @@ def main():
                     "device list, e.g. 0,1,2,3 (a device may repeat: rehearsal on one GPU); the gather and the assembly on the "
                     "first device are inside the timed step.  Not combined with torch.distributed.run")
     ap.add_argument("--corrected-spp", type=int, default=64, help="spp of the corrected-sampling (r2 = U) frame")
+    ap.add_argument("--n1-ms", type=float, default=0.0,
+                    help="ms_per_step of the N=1 line of the same command: with it an N>1 line also carries parallel_efficiency "
+                         "= n1_ms / (N x ms_per_step)")
     ap.add_argument("--reorder", type=lambda v: int(v, 0), default=0,
                     help="experiment (A/B library only, VMX_LIB=build/libvermilion_hip_ab.so): bounce reordering key, tools/sort_probe.py")
     args = ap.parse_args()
@@ -127,13 +138,13 @@ def main():
     local = torch.empty((rows, W, 5), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step(early_stop=False, counters=False, sampling=va.VMX_SAMPLING_PARITY, pipeline=0):
+    def step(early_stop=False, counters=False, sampling=va.VMX_SAMPLING_PARITY, pipeline=HEADLINE_FORM, times=None):
         opts = va.make_opts(seed=args.seed, early_stop=early_stop, sampling=sampling, rank=rank,
                             world=world, stripe_rows=stripe, collect_counters=counters, reorder=args.reorder, pipeline=pipeline)
         st = sc.render_device(cam, opts, local.data_ptr(), stream)
         st["kernels"] = sc.timings()  # per-kernel hipEvent durations of this frame (on the render stream)
         src = local if args.backend == "nccl" or world == 1 else local.cpu()
-        frame = vdist.gather_frame(src, W, H, stripe, rank, world, dst=0)
+        frame = vdist.gather_frame(src, W, H, stripe, rank, world, dst=0, times=times)
         return st, frame
 
     def sync():
@@ -141,14 +152,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(k, **kw):
+    exchange = {}  # N > 1: the exchange step of the timed headline steps, apart from the rendering
+
+    def timed(k, exchange_out=None, **kw):
         # (a generation-2 Python garbage collection inside a timed region showed up as +36 ms on the three
         # early-stop frames whenever --steps happened to place it there: collect first, keep it out)
         gc.collect()
         gc.disable()
+        times = vdist.ExchangeTimes() if (world > 1 and exchange_out is not None) else None
         sync()
         t0 = time.perf_counter()
-        stats = [step(**kw)[0] for _ in range(k)]
+        stats = [step(times=times, **kw)[0] for _ in range(k)]
         sync()
         dt = time.perf_counter() - t0
         gc.enable()
@@ -160,13 +174,33 @@ def main():
             r = torch.tensor([rays], dtype=torch.float64, device=rdev)
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
             dt, rays = float(t.item()), float(r.item())
+            if times is not None:
+                # per rank: device time of its stripes' render, of its part in the gather (hipEvents on the stream the
+                # collective is ordered on; wall clock for the gloo rehearsal) and, on the root, of k_assemble
+                mine = torch.tensor([sum(s["ms_device"] for s in stats) / k, times.ms("gather") / k, times.ms("assemble") / k],
+                                    dtype=torch.float64, device=rdev)
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                allr = torch.stack(allr).cpu().numpy()
+                exchange_out.update({
+                    "slowest_rank_render_ms": round(float(allr[:, 0].max()), 3),
+                    "fastest_rank_render_ms": round(float(allr[:, 0].min()), 3),
+                    "rank_render_ms": [round(float(x), 3) for x in allr[:, 0]],
+                    # a rank that finishes early waits inside the collective for the slowest one: the root's figure is
+                    # the one that lies on the frame's critical path
+                    "gather_ms": round(float(allr[0, 1]), 3),
+                    "gather_ms_by_rank": [round(float(x), 3) for x in allr[:, 1]],
+                    "assemble_ms": round(float(allr[0, 2]), 3),
+                    "what": "per timed step: hipEvent pairs around each rank's render, around dist.gather (RCCL over xGMI) "
+                            "and around k_assemble on the root; a rank's gather time includes its wait for the slowest rank",
+                })
         return dt, rays, stats
 
     # counters pass (instrumented kernels, untimed): algorithmic bytes of this exact frame
     cst, _ = step(counters=True)
     for _ in range(args.warmup):
         step()
-    dt, rays, stats = timed(args.steps)
+    dt, rays, stats = timed(args.steps, exchange_out=exchange)
     ms_per_step = dt / args.steps * 1e3
     value = rays / dt / 1e6
 
@@ -176,23 +210,27 @@ def main():
         step(early_stop=True)
         es_k = max(1, min(args.steps, 3))
         es_dt, es_rays, es_stats = timed(es_k, early_stop=True)
+        step(early_stop=True, pipeline=0)
+        esd_dt, esd_rays, esd_stats = timed(es_k, early_stop=True, pipeline=0)
 
-    # The headline frame settles the Radiance steps that end by the path's own draws without the part of RayCast nobody
-    # reads for them (the hit's normal and uv, the wall spheres: DESIGN.md 5.1) — every ray is still traced to its nearest
-    # triangle and counted.  For comparison, the same frame with every step shaded in full (vmx_opts.reserved[0] bit 8):
-    full_info = None
+    # The library's DEFAULT form of the same frame: whoever creates a ray also notes whether the Radiance step that traces
+    # it is the path's last one by the path's own draws; the traversal kernels settle such rays where they
+    # finish — BVH query, the light spheres' reach test, counted — and hand only the others to k_shade.  Bit-identical
+    # frame in less time, but its settled rays are not full RayCasts, so it is a frame time, not the headline's ray rate.
+    sorted_info = None
     if not args.no_extras:
         _, g0 = step()
         g0 = g0.clone() if g0 is not None else None
-        _, g1 = step(pipeline=0x100)
+        _, g1 = step(pipeline=0)
         fs_k = max(1, min(args.steps, 3))
-        fs_dt, fs_rays, fs_stats = timed(fs_k, pipeline=0x100)
-        full_info = {
-            "what": "the headline frame with every Radiance step shaded in full (one-phase k_shade over all paths, hit records "
-                    "for all rays; vmx_opts.reserved[0] bit 8) instead of the traversal kernels settling the steps that end by "
-                    "the path's own draws",
+        fs_dt, fs_rays, fs_stats = timed(fs_k, pipeline=0)
+        sorted_info = {
+            "what": "the library's default form of the headline frame (vmx_opts.reserved[0] = 0): the traversal kernels settle "
+                    "the rays whose Radiance step ends by the path's own draws (BVH query + light-sphere reach test, counted) "
+                    "and hand the others to k_shade as records; for the settled rays the wall spheres, normal and uv are "
+                    "never evaluated, so its ray rate is a BVH-query rate, not SURVEY 8(d)'s",
             "frame_bit_identical_to_headline": bool(torch.equal(g0.view(torch.int32), g1.view(torch.int32))) if rank == 0 else None,
-            "ms_per_frame": round(fs_dt / fs_k * 1e3, 3), "Mrays_per_s": round(fs_rays / fs_dt / 1e6, 2),
+            "ms_per_frame": round(fs_dt / fs_k * 1e3, 3), "bvh_queries_Mrays_per_s": round(fs_rays / fs_dt / 1e6, 2),
             "rays_per_frame": int(fs_rays / fs_k),
             "kernel_ms": {k: round(sum(x["kernels"][k]["ms"] for x in fs_stats) / fs_k, 3)
                           for k in fs_stats[0]["kernels"] if fs_stats[0]["kernels"][k]["launches"]},
@@ -208,12 +246,12 @@ def main():
         for es in (False, True):
             _, f0 = step(early_stop=es)
             f0 = f0.clone() if f0 is not None else None  # (one GPU: the frame is the render target itself)
-            _, f1 = step(early_stop=es, sampling=ELIDE)
+            _, f1 = step(early_stop=es, sampling=ELIDE, pipeline=0)
             if rank == 0:
                 same.append(bool(torch.equal(f0.view(torch.int32), f1.view(torch.int32))))
         el_k = max(1, min(args.steps, 3))
-        el_dt, el_rays, el_stats = timed(el_k, sampling=ELIDE)
-        ele_dt, ele_rays, ele_stats = timed(el_k, early_stop=True, sampling=ELIDE)
+        el_dt, el_rays, el_stats = timed(el_k, sampling=ELIDE, pipeline=0)
+        ele_dt, ele_rays, ele_stats = timed(el_k, early_stop=True, sampling=ELIDE, pipeline=0)
 
         def kms(sts):
             return {k: round(sum(x["kernels"][k]["ms"] for x in sts) / len(sts), 3)
@@ -221,11 +259,11 @@ def main():
         el_info = {
             "what": "the same two frames with VMX_SAMPLING_ELIDE_DEAD (opt-in): rays whose Radiance step provably cannot change "
                     "the path's colour are not traced (vmx_kernels.hip: step_is_dead); rays_per_frame counts traced rays only",
-            "frames_bit_identical_to_default": all(same) if rank == 0 else None,
+            "frames_bit_identical_to_headline": all(same) if rank == 0 else None,
             "fixed_count": {"ms_per_frame": round(el_dt / el_k * 1e3, 3), "rays_per_frame": int(el_rays / el_k),
-                            "speedup_vs_default": round(ms_per_step / (el_dt / el_k * 1e3), 2), "kernel_ms": kms(el_stats)},
+                            "speedup_vs_headline": round(ms_per_step / (el_dt / el_k * 1e3), 2), "kernel_ms": kms(el_stats)},
             "early_stop": {"ms_per_frame": round(ele_dt / el_k * 1e3, 3), "rays_per_frame": int(ele_rays / el_k),
-                           "speedup_vs_default": round((es_dt / es_k) / (ele_dt / el_k), 2) if es_k else None,
+                           "speedup_vs_headline_form": round((es_dt / es_k) / (ele_dt / el_k), 2) if es_k else None,
                            "kernel_ms": kms(ele_stats)},
         }
 
@@ -266,6 +304,7 @@ def main():
 
     # §8 f-1 quality builder (binned SAH, not the reference's topology): same frame, extra figure only
     q_info = None
+    cq_info = None
     if world == 1 and not args.no_extras:
         # ... and the same quality from the GPU builder (PLOC): scene creation is then a per-frame operation
         va.Scene(pos, nrm, uv, device=dev_index, builder=va._lib.VMX_BVH_PLOC).close()  # first hipcub launches
@@ -291,6 +330,29 @@ def main():
             "inner_visits_per_ray": round(pc["primary"]["inner_visits"] / max(pc["primary"]["rays"], 1), 2),
             "bvh": {k: psc.describe()[k] for k in ("n_nodes", "max_depth")},
         }
+        # `corrected` sampling over the same GPU-built quality tree: the configuration a user of a real cosine-lobe tracer
+        # would pick (bounce rays go from ~95 to ~40 node visits)
+        cq_info = None
+        if args.corrected_spp >= 4:
+            ccam = va.make_camera(c["position"], c["rotation_deg"], W, H, args.corrected_spp, back_size=(3.6, 3.6 * H / W))
+            copts = va.make_opts(seed=args.seed, early_stop=False, sampling=va.VMX_SAMPLING_CORRECTED)
+            psc.render_device(ccam, copts, local.data_ptr(), stream)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            cq = psc.render_device(ccam, copts, local.data_ptr(), stream)
+            torch.cuda.synchronize(dev)
+            cqdt = time.perf_counter() - t0
+            cqk = psc.timings()
+            cqrays = cq["rays_primary"] + cq["rays_secondary"]
+            cq_info = {
+                "what": "corrected sampling (r2 = U) over the tree the GPU builds by parallel locally-ordered clustering "
+                        f"(VMX_BVH_PLOC), fixed {args.corrected_spp} spp: oracle parity over the exported tree "
+                        "(tests/test_gpu_parity.py::test_quality_bvh_builder_f1), no image-parity claim against the reference",
+                "spp": args.corrected_spp, "ms_per_frame": round(cqdt * 1e3, 3), "Mrays_per_s": round(cqrays / cqdt / 1e6, 2),
+                "rays_per_frame": int(cqrays),
+                "kernel_ms": {k: round(v["ms"], 3) for k, v in cqk.items() if v["launches"]},
+                "kernel_launches": {k: int(v["launches"]) for k, v in cqk.items() if v["launches"]},
+            }
         psc.close()
         qsc = va.Scene(pos, nrm, uv, device=dev_index, builder=va._lib.VMX_BVH_SAH)
         qopts = va.make_opts(seed=args.seed, early_stop=False, collect_counters=True)
@@ -324,10 +386,12 @@ def main():
         ppath = os.path.join(ROOT, "profiles", "counters.json")
         if os.path.exists(ppath) and world == 1 and (W, H, spp, args.scene) == (1920, 1080, 256, "sponza260k"):
             try:
-                prof = json.load(open(ppath))["kernels"]
+                pj = json.load(open(ppath))
+                # (counters are a property of binary + workload + pipeline form: only those collected on this headline form)
+                prof = pj["kernels"] if pj.get("form") == HEADLINE_FORM else None
                 # one timed interval of the library (vmx_timings) covers both shading phases: add their counters up
                 # (instructions, cache accesses and HBM bytes are additive; lane utilisation weighted by instructions)
-                for stage in ("camera", "bounce"):
+                for stage in ("camera", "bounce") if prof else ():
                     a, b = prof.get("shade_ends_" + stage, {}).get("derived"), prof.get("shade_" + stage, {}).get("derived")
                     if a and b:
                         va_, vb_ = a.get("valu_wave_insts_per_launch", 0.0), b.get("valu_wave_insts_per_launch", 0.0)
@@ -358,21 +422,34 @@ def main():
                                         "from": "counters pass, bounce stage averages x rays of the first generation"}
 
         def kernel_roof(name):
-            """VALU-issue roofline of one kernel: wave-level VALU instructions per launch (rocprofv3 PMC of this
-            exact frame, profiles/counters.json) / the launch duration measured here"""
+            """Roofline of one kernel against the VALU issue peak (the roof that binds: DESIGN.md 6).
+            frac / achieved = the WORK-based figure: the lane-operations the reference's tests need (counters pass of this
+            exact frame x A_INNER / A_TRI), as full 64-lane instructions, over the launch duration measured here — it cannot
+            exceed 1 and does not grow with wasted instructions.  issue_frac = wave-level VALU instructions actually issued
+            (rocprofv3 PMC of this exact frame, profiles/counters.json) over the same duration: how busy the issue slots are."""
             n = max(klaunch[name], 1)
             avg_ms = kms[name] * args.steps / n
             if n > args.steps:  # several launches per step: the counters are those of the longest one, so is the duration
                 avg_ms = sum(s["kernels"][name]["longest_ms"] for s in stats) / args.steps
             r = {"kernel": KERNEL_TEXT.get(name, name), "avg_launch_ms": round(avg_ms, 4),
-                 "launches_per_step": n // max(args.steps, 1), "ms_per_step": round(kms[name], 3)}
+                 "launches_per_step": n // max(args.steps, 1), "ms_per_step": round(kms[name], 3),
+                 "bound": "valu_issue", "achieved": None, "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "Gwave-inst/s",
+                 "frac": None, "traffic": None}
+            w = work.get(name)
+            if w and avg_ms > 0:
+                need = w["inner_visits"] * A_INNER[name] + w["tri_tests"] * A_TRI[name]
+                ach = need / 64 / (avg_ms * 1e-3)
+                r.update({"achieved": round(ach / 1e9, 2), "frac": round(ach / VALU_ISSUE_PEAK, 4),
+                          "useful_valu_frac": round(ach / VALU_ISSUE_PEAK, 4),
+                          "useful_lane_ops_per_ray": round(need / max(w["rays"], 1), 1),
+                          "work": {"rays": int(w["rays"]), "inner_visits": int(w["inner_visits"]), "tri_tests": int(w["tri_tests"]),
+                                   "A_inner": A_INNER[name], "A_tri": A_TRI[name], "from": w["from"]}})
             d = (prof or {}).get(name, {}).get("derived")
             if d and avg_ms > 0:
                 # (a kernel launched more than once per step: counters are those of its longest launch; the bench
                 # frame launches each traversal kernel once)
-                ach = d["valu_wave_insts_per_launch"] / (avg_ms * 1e-3)
-                r.update({"bound": "valu_issue", "achieved": round(ach / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
-                          "unit": "Gwave-inst/s", "frac": round(ach / VALU_ISSUE_PEAK, 4),
+                iss = d["valu_wave_insts_per_launch"] / (avg_ms * 1e-3)
+                r.update({"issue_achieved": round(iss / 1e9, 2), "issue_frac": round(iss / VALU_ISSUE_PEAK, 4),
                           "traffic": d.get("hbm_bytes_per_launch"),
                           "valu_wave_insts_per_launch": int(d["valu_wave_insts_per_launch"]),
                           # scalar ALU instructions share the issue slots (tools/sload_probe.hip): the same rate with them
@@ -386,7 +463,8 @@ def main():
                           if "l1_accesses_per_launch" in d else None,
                           "hbm_frac_measured": round(d["hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                           if "hbm_bytes_per_launch" in d else None})
-                w = work.get(name)
+                if "frac" in r and r["frac"] is None:  # a kernel without a work model (shading, fused tail): issue occupancy only
+                    r["note"] = "no work model for this kernel: issue_frac is the occupancy of the issue slots, not a work-based fraction"
                 if w:
                     # lane-operations the VALU executed per ray, and per-launch bytes through the vector L1 (64 B per
                     # tag lookup) and the scalar cache (64 B per s_load_dwordx16) next to the algorithmic bytes
@@ -397,26 +475,36 @@ def main():
                         "vector_l1": int(d["l1_accesses_per_launch"] * 64) if "l1_accesses_per_launch" in d else None,
                         "scalar_cache": int(c["SQ_INSTS_SMEM"] * 64) if "SQ_INSTS_SMEM" in c else None,
                         "algorithmic": int(w["alg_bytes"])}
-            w = work.get(name)
-            if w and avg_ms > 0:
-                # work against the roof: the lane-operations the reference's tests NEED, as full 64-lane instructions,
-                # over the launch time and the VALU issue peak — cannot exceed 1, does not grow with wasted instructions
-                need = w["inner_visits"] * A_INNER[name] + w["tri_tests"] * A_TRI[name]
-                r["useful_valu_frac"] = round(need / 64 / (avg_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
-                r["useful_lane_ops_per_ray"] = round(need / max(w["rays"], 1), 1)
-                r["work"] = {"rays": int(w["rays"]), "inner_visits": int(w["inner_visits"]), "tri_tests": int(w["tri_tests"]),
-                             "A_inner": A_INNER[name], "A_tri": A_TRI[name], "from": w["from"]}
             return r
 
         roof = kernel_roof(dominant)
-        if "bound" not in roof:  # no PMC profile for this configuration: say so instead of inventing a fraction
-            roof.update({"bound": "valu_issue", "achieved": None, "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
-                         "unit": "Gwave-inst/s", "frac": None, "traffic": None,
-                         "note": "profiles/counters.json holds no counters for this workload"})
-        roof["useful_valu_frac_what"] = ("(inner_visits x A_inner + tri_tests x A_tri) / 64 / launch duration / VALU issue peak: the "
-                                         "share of the issue roof spent on arithmetic the reference's tests need (frac counts "
-                                         "every instruction issued)")
-        roof["source"] = "profiles/counters.json (rocprofv3 --pmc, tools/pmc.sh + tools/make_counters.py) x live hipEvent durations"
+        if not prof:  # no PMC profile for this configuration: say so instead of inventing an issue fraction or a traffic figure
+            roof["note"] = ("profiles/counters.json holds no counters for this workload / pipeline form: traffic and issue_frac "
+                            "are null, frac is the work-based figure from the live counters pass")
+        roof["frac_what"] = ("(inner_visits x A_inner + tri_tests x A_tri) / 64 / launch duration / VALU issue peak: the share of the "
+                             "issue roof spent on arithmetic the reference's tests need (bbox.cpp:70-83, bvh.cpp:103-114, "
+                             "triangle.cpp:4-54); issue_frac counts every VALU instruction issued")
+        roof["source"] = ("work: the counters pass of this run (vmx_opts.collect_counters, equal to the oracle's visit counts); "
+                          "issued instructions and HBM bytes: profiles/counters.json (rocprofv3 --pmc, tools/pmc.sh + "
+                          "tools/make_counters.py); durations: live hipEvent pairs on the render stream")
+        # HBM bytes of the whole frame (sum over its kernels of the PMC bytes per launch x launches per step) against the
+        # 8 TB/s peak over the step: north_star's "share of the HBM roofline" — not the binding roof of this path
+        if prof:
+            hb, missing = 0.0, []
+            for k in kms:
+                if kms[k] <= 0:
+                    continue
+                d_ = prof.get(k, {}).get("derived", {})
+                if "hbm_bytes_per_launch" in d_:
+                    hb += d_["hbm_bytes_per_launch"] * max(klaunch[k] // max(args.steps, 1), 1)
+                else:
+                    missing.append(k)
+            roof["hbm_frac_whole_frame"] = round(hb / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roof["hbm_bytes_whole_frame"] = int(hb)
+            if missing:
+                roof["hbm_frac_whole_frame_missing_kernels"] = missing
+        else:
+            roof["hbm_frac_whole_frame"] = None
         roof["other_kernels"] = {k: kernel_roof(k) for k in ("trace_camera", "trace_bounce", "shade_camera", "tail")
                                  if k != dominant and kms.get(k, 0) > 0}
         # SURVEY §8(d)'s algorithmic bytes, kept as the secondary view: the scene (34 MB) is cache-resident, so
@@ -453,9 +541,10 @@ def main():
                 "workload": f"{args.scene} ({desc['ntris']} tris, procedural Sponza stand-in) {W}x{H} {spp}spp, "
                             "reference sampling (r2=10U), fixed spp (early stop off), reference sphere table",
                 "rays_per_frame": int(rays / args.steps),
-                "ray": "every ray the reference traces, traced to its nearest triangle (BVH::getIntersection) and counted; the "
-                       "rest of RayCast (normal, uv, wall spheres) is evaluated for the rays whose Radiance step reads it — "
-                       "DESIGN.md 5.1; full_shading_frame gives the frame with it evaluated for all",
+                "ray": "one full MeshEngine::RayCast (meshEngine.cpp:239-509): BVH::getIntersection, the whole sphere table, "
+                       "normal and uv — for EVERY counted ray (SURVEY 8(d)); vmx_opts.reserved[0] bit 8.  The library's "
+                       "default form of this frame and the VMX_SAMPLING_ELIDE_DEAD form render the same bits in less time: "
+                       "frame_ms, sorted_frame, elided_frame",
                 "parallelism": f"stripes{stripe}x{world}" if world > 1 else "single",
                 "bvh": {"nodes": desc["n_nodes"], "max_depth": desc["max_depth"], "leaf_size": desc["leaf_size"]},
             },
@@ -470,9 +559,19 @@ def main():
             "whole_frame_alg_GBs": round((alg_bytes(cst["primary"]) + alg_bytes(cst["bounce"])) / (ms_per_step * 1e-3) / 1e9, 1)
             if world == 1 else None,
         }
+        if sorted_info and el_info:
+            # wall-clock per frame is the second half of BASELINE.json's metric: three bit-identical frames
+            out["frame_ms"] = {
+                "every_ray_a_full_RayCast (headline)": round(ms_per_step, 3),
+                "rays_settled_where_they_finish (library default)": sorted_info["ms_per_frame"],
+                "VMX_SAMPLING_ELIDE_DEAD": el_info["fixed_count"]["ms_per_frame"],
+                "bit_identical": bool(sorted_info["frame_bit_identical_to_headline"] and el_info["frames_bit_identical_to_headline"]),
+            }
         if es_k:
             out["reference_frame"] = {
-                "what": "same frame with the reference's early-stop rule on (pathtracer.cpp:290-311)",
+                "what": "same frame with the reference's early-stop rule on (pathtracer.cpp:290-311), every ray a full RayCast "
+                        "like the headline; library_default_ms: the library's default form of it",
+                "library_default_ms": round(esd_dt / es_k * 1e3, 3),
                 "ms_per_frame": round(es_dt / es_k * 1e3, 3),
                 "Mrays_per_s": round(es_rays / es_dt / 1e6, 2),
                 "rays_per_frame": int(es_rays / es_k),
@@ -486,8 +585,14 @@ def main():
         if q_info:
             out["quality_bvh"] = q_info
             out["quality_bvh_gpu_built"] = p_info
-        if full_info:
-            out["full_shading_frame"] = full_info
+        if cq_info:
+            out["corrected_frame_quality_bvh"] = cq_info
+        if sorted_info:
+            out["sorted_frame"] = sorted_info
+        if exchange:
+            out["exchange"] = exchange
+        if world > 1 and args.n1_ms > 0:
+            out["parallel_efficiency"] = round(args.n1_ms / (world * ms_per_step), 4)
         if el_info:
             out["elided_frame"] = el_info
         if corr_info:
@@ -496,11 +601,16 @@ def main():
             out["bruteforce_frame"] = bf_info
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pos, nrm, uv, c, W, H, args.cpu_spp, args.seed)
-        print(json.dumps(out), flush=True)
+    # everything this process holds is released before the line goes out, so that nothing of it outlives the line
     sc.close()
+    del local
+    gc.collect()
+    torch.cuda.empty_cache()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def main_multi(args):
@@ -522,7 +632,7 @@ def main_multi(args):
     root = torch.device("cuda", devices[0])
     frame = torch.empty((H, W, 5), dtype=torch.float32, device=root)
     ms = va.MultiScene(pos, nrm, uv, devices=devices)
-    opts = va.make_opts(seed=args.seed, early_stop=False, sampling=va.VMX_SAMPLING_PARITY, stripe_rows=stripe)
+    opts = va.make_opts(seed=args.seed, early_stop=False, sampling=va.VMX_SAMPLING_PARITY, stripe_rows=stripe, pipeline=HEADLINE_FORM)
 
     def sync():
         for d in sorted(set(devices)):
@@ -534,12 +644,15 @@ def main_multi(args):
     gc.disable()
     sync()
     t0 = time.perf_counter()
-    stats = [ms.render_device(cam, opts, frame.data_ptr()) for _ in range(args.steps)]
+    stats, xch = [], []
+    for _ in range(args.steps):
+        stats.append(ms.render_device(cam, opts, frame.data_ptr()))
+        xch.append(ms.timings())  # the exchange step of this frame, timed apart from the rendering (vmx_multi_timings)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
     rays = float(sum(s["rays_primary"] + s["rays_secondary"] for s in stats))
-    es_opts = va.make_opts(seed=args.seed, early_stop=True, stripe_rows=stripe)
+    es_opts = va.make_opts(seed=args.seed, early_stop=True, stripe_rows=stripe, pipeline=HEADLINE_FORM)
     ms.render_device(cam, es_opts, frame.data_ptr())
     sync()
     t0 = time.perf_counter()
@@ -554,6 +667,7 @@ def main_multi(args):
             "workload": f"{args.scene} ({ms.ntris} tris, procedural Sponza stand-in) {W}x{H} {spp}spp, reference sampling "
                         "(r2=10U), fixed spp (early stop off), reference sphere table",
             "rays_per_frame": int(rays / args.steps),
+            "ray": "one full MeshEngine::RayCast for every counted ray (vmx_opts.reserved[0] bit 8), as in the N=1 line",
             "parallelism": f"one process, vmx_multi over devices {devices}, stripes{stripe}x{world}, device-to-device gather "
                            "on the first device",
             "distinct_devices": len(set(devices)),
@@ -561,13 +675,30 @@ def main_multi(args):
         "roofline": {"bound": "valu_issue", "achieved": None, "peak": round(VALU_ISSUE_PEAK / 1e9, 1), "unit": "Gwave-inst/s",
                      "frac": None, "traffic": None,
                      "note": "per-kernel counters are a single-device figure: see the N=1 line (python bench.py)"},
+        **({"parallel_efficiency": round(args.n1_ms / (world * (dt / args.steps * 1e3)), 4)} if args.n1_ms > 0 else {}),
         "slowest_device_ms_per_step": round(sum(s["ms_device"] for s in stats) / args.steps, 3),
+        "exchange": {
+            "slowest_rank_render_ms": round(sum(x["slowest_render_ms"] for x in xch) / len(xch), 3),
+            "rank_render_ms": [round(sum(x["render_ms"][r] for x in xch) / len(xch), 3) for r in range(world)],
+            "gather_ms": round(sum(x["gather_ms"] for x in xch) / len(xch), 3),
+            "gather_ms_by_rank": [round(sum(x["copy_ms"][r] for x in xch) / len(xch), 3) for r in range(world)],
+            "assemble_ms": round(sum(x["assemble_ms"] for x in xch) / len(xch), 3),
+            "wall_ms": round(sum(x["wall_ms"] for x in xch) / len(xch), 3),
+            "routes": [{"device": d, "route": {2: "root's own device", 1: "direct peer copy (xGMI)", 0: "staged through the host"}[r]}
+                       for d, r in ms.routes()],
+            "what": "per timed step: hipEvent pairs on each replica's stream around its render and around its stripes' "
+                    "device-to-device copy into the root's gather buffer, and on the root's stream around k_assemble; wall_ms is "
+                    "the host clock from handing the jobs out to the assembled frame",
+        },
         "reference_frame": {"what": "same frame with the reference's early-stop rule on (pathtracer.cpp:290-311)",
                             "ms_per_frame": round(es_dt * 1e3, 3),
                             "Mrays_per_s": round((es["rays_primary"] + es["rays_secondary"]) / es_dt / 1e6, 2)},
     }
-    print(json.dumps(out), flush=True)
     ms.close()
+    del frame
+    gc.collect()
+    torch.cuda.empty_cache()
+    print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(pos, nrm, uv, c, W, H, spp, seed):

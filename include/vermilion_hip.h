@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VMX_ABI_VERSION 1
+#define VMX_ABI_VERSION 2 /* 2: vmx_camera.rotation_units / rotation_rad, vmx_multi_timings */
 
 /* status codes */
 #define VMX_OK 0
@@ -94,13 +94,20 @@ typedef struct vmx_sphere {
  * Camera constructor's conversion (core/camera/camera.cpp:43-47):
  *   mRotation = (-rx, -ry, +rz) * 3.1415926535 / 180.
  */
+#define VMX_ROTATION_DEGREES 0u /* rotation_deg = cameraSettings.rotation; the library applies camera.cpp:43-47 */
+#define VMX_ROTATION_RADIANS 1u /* rotation_rad = Camera::mRotation as it stands (already negated in x, y and in
+                                   radians): what an Integrator holds — PathTracer::Render reads mRotation, not the
+                                   settings (pathtracer.cpp:219-221) — passed through without a degree round trip */
 typedef struct vmx_camera {
     float position[3];     /* cameraSettings.position                        */
-    float rotation_deg[3]; /* cameraSettings.rotation (degrees)              */
+    float rotation_deg[3]; /* cameraSettings.rotation (degrees); read when rotation_units == VMX_ROTATION_DEGREES */
     float back_distance;   /* cameraSettings.fBackDistance -> mDistToFilm    */
     float back_size[2];    /* cameraSettings.fBackSizeX/Y  -> sensorSizeX/Y  */
     uint32_t image_res[2]; /* imageResX, imageResY                           */
     uint32_t rays_per_pixel; /* raysPerPixel -> uSamplesPerPixel             */
+    uint32_t rotation_units; /* VMX_ROTATION_DEGREES (0, the default of a zeroed struct) or VMX_ROTATION_RADIANS */
+    float rotation_rad[3]; /* Camera::mRotation (camera.h, set at camera.cpp:43-47); read when rotation_units ==
+                              VMX_ROTATION_RADIANS: the three angles glm::rotate gets at pathtracer.cpp:219-221 */
 } vmx_camera;
 
 typedef struct vmx_opts {
@@ -326,6 +333,19 @@ uint32_t vmx_multi_world(const vmx_multi *m);
  * copy (xGMI), 0 staged through the host (peer access unavailable; a warning went to stderr at creation).
  * Either array may be NULL; each holds vmx_multi_world() ints. */
 int vmx_multi_routes(const vmx_multi *m, int *devices, int *routes);
+/* The exchange step of the LAST vmx_multi_render* call, timed apart from the rendering ("gather time
+ * separately"): hipEvent pairs on each replica's stream around its stripes' copy into the root's gather buffer and on the
+ * root's stream around the de-interleave kernel.  render_ms / copy_ms: per entry of the device list
+ * (vmx_multi_world() doubles each), either may be NULL. */
+typedef struct vmx_multi_times {
+    double slowest_render_ms; /* max over the replicas of vmx_stats.ms_device of its stripes' render  */
+    double gather_ms;         /* max over the replicas of its device-to-device (or staged) copy        */
+    double gather_sum_ms;     /* sum of those copies                                                    */
+    double assemble_ms;       /* k_assemble on devices[0]                                               */
+    double wall_ms;           /* host clock from handing the jobs out to the assembled frame            */
+    uint32_t world, pad;
+} vmx_multi_times;
+int vmx_multi_timings(const vmx_multi *m, vmx_multi_times *out, double *render_ms, double *copy_ms);
 int vmx_multi_bind_texture(vmx_multi *m, const float *data, uint32_t width, uint32_t height, uint32_t channels);
 /* whole frame (W*H*5 floats) into a caller-owned HOST buffer / into DEVICE memory on devices[0];
  * stats: rays and samples summed over the devices, times = the slowest device's */

@@ -448,12 +448,17 @@ inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
  * x0 = mix64(seed ^ (pixel << 32 | k)).  (DESIGN.md "RNG") */
 struct Xoshiro {
     uint64_t s0, s1, s2, s3;
+    /* Stream of sample k of pixel p — this build's own definition (the reference seeds a thread-local mt19937_64 from
+     * std::random_device, pathtracer.cpp:231): two mix64 per pixel, three 64-bit multiplies per sample (the kernels key
+     * the pixel half once per wave; vmx_kernels.hip: rng_pixel_key / rng_init_keyed) */
     void init(uint64_t seed, uint32_t pixel, uint32_t k) {
-        uint64_t x = mix64(seed ^ (((uint64_t)pixel << 32) | (uint64_t)k));
-        s0 = splitmix64(x);
-        s1 = splitmix64(x);
-        s2 = splitmix64(x);
-        s3 = splitmix64(x);
+        const uint64_t a = mix64(seed ^ ((uint64_t)pixel << 32));
+        const uint64_t b = mix64(a + 0x9E3779B97F4A7C15ull);
+        s0 = mix64(a + (uint64_t)k);
+        const uint64_t t = (s0 ^ b) * 0xD6E8FEB86659FD93ull;
+        s1 = t ^ (t >> 32);
+        s2 = rotl64(s0, 24) ^ b;
+        s3 = rotl64(s1, 37) ^ a;
     }
     uint64_t next() {
         uint64_t r = rotl64(s1 * 5, 7) * 9;
@@ -764,6 +769,8 @@ inline Mat3 camera_matrix(const vmx_camera &cam) {
     float rx = (float)(-cam.rotation_deg[0] * 3.1415926535 / 180);
     float ry = (float)(-cam.rotation_deg[1] * 3.1415926535 / 180);
     float rz = (float)(cam.rotation_deg[2] * 3.1415926535 / 180);
+    /* VMX_ROTATION_RADIANS: the caller holds Camera::mRotation itself (what pathtracer.cpp:219-221 reads) */
+    if (cam.rotation_units == VMX_ROTATION_RADIANS) rx = cam.rotation_rad[0], ry = cam.rotation_rad[1], rz = cam.rotation_rad[2];
     Mat3 m = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
     m = rotate(m, ry, v3(0, 1, 0)); /* pathtracer.cpp:219 */
     m = rotate(m, rx, v3(1, 0, 0)); /* :220 */
@@ -790,7 +797,17 @@ template <class Rng, class InitFn>
 void render_rows(const orc_scene &sc, const vmx_camera &cam, const vmx_opts &opts, float *out,
                  vmx_stats *stats, int threads, InitFn init_rng) {
     const uint32_t W = cam.image_res[0], H = cam.image_res[1], spp = cam.rays_per_pixel;
-    const uint64_t npix = (uint64_t)W * H;
+    /* Pixel subset (test infrastructure: the reference always renders every pixel).  With opts.world > 1 only the rows
+     * of the stripes s with s % world == rank are rendered — the sharding of vmx_render — and `out` holds those rows
+     * packed in ascending order; pixels are independent (pathtracer.cpp:226-227), sample streams are keyed by the GLOBAL
+     * pixel index, so a row here equals the same row of the whole frame.  This is what lets the tests put 1/16 of a
+     * full-size frame (BASELINE.json configs 3, 4) against the HIP path in seconds. */
+    const uint32_t world = opts.world <= 1 ? 1u : opts.world, rank = opts.world <= 1 ? 0u : opts.rank;
+    const uint32_t stripe = opts.stripe_rows ? opts.stripe_rows : 16u;
+    std::vector<uint32_t> rows;
+    for (uint32_t y = 0; y < H; ++y)
+        if ((y / stripe) % world == rank) rows.push_back(y);
+    const uint64_t npix = (uint64_t)W * rows.size();
     const Mat3 M = camera_matrix(cam);
     const V3 origin = v3(cam.position[0], cam.position[1], cam.position[2]);
     const bool count_nodes = opts.collect_counters != 0;
@@ -805,7 +822,8 @@ void render_rows(const orc_scene &sc, const vmx_camera &cam, const vmx_opts &opt
         Rng rng;
         PathStats st;
 #pragma omp for schedule(dynamic, 1)
-        for (uint64_t p = 0; p < npix; ++p) { /* pathtracer.cpp:226-227 */
+        for (uint64_t lp = 0; lp < npix; ++lp) { /* pathtracer.cpp:226-227 */
+            const uint64_t p = (uint64_t)rows[lp / W] * W + lp % W; /* global pixel index (all of them when world <= 1) */
             V4 accum = {0, 0, 0, 0};
             uint32_t nTotal = 0;
             for (uint16_t sx = 0; sx < 2; ++sx) {
@@ -827,7 +845,7 @@ void render_rows(const orc_scene &sc, const vmx_camera &cam, const vmx_opts &opt
                     }
                 }
             }
-            float *px = out + p * 5; /* :318-324, camera.cpp:106-113 */
+            float *px = out + lp * 5; /* :318-324, camera.cpp:106-113 */
             px[0] = std::max(std::min(accum.x / nTotal, 1.f), 0.f);
             px[1] = std::max(std::min(accum.y / nTotal, 1.f), 0.f);
             px[2] = std::max(std::min(accum.z / nTotal, 1.f), 0.f);
@@ -1255,6 +1273,33 @@ void orc_trig_compare_libm(uint32_t lo_bits, uint32_t hi_bits, uint64_t *cos_dif
     }
     *cos_diff = dc;
     *sin_diff = ds;
+}
+
+/* The kernels divide by the image width / height (pathtracer.cpp:251-252, in double) with a reciprocal and one FMA
+ * correction (vmx_kernels.hip: div_by_count).  For every float fx with bit pattern in [lo_bits, hi_bits] and both
+ * signs: how often float(((double)fx - 0.25) / n - 0.5) — what the reference computes — differs from the same with
+ * the three-operation quotient; also counts the cases where the double quotients themselves differ.  Must be 0 / 0. */
+void orc_check_div_by_count(uint32_t n, uint32_t lo_bits, uint32_t hi_bits, uint64_t *float_diff, uint64_t *double_diff) {
+    uint64_t df = 0, dd = 0;
+    const double y = 1.0 / (double)n;
+#pragma omp parallel for reduction(+ : df, dd) schedule(static)
+    for (uint64_t b = lo_bits; b <= (uint64_t)hi_bits; ++b) {
+        for (uint32_t sign = 0; sign < 2; ++sign) {
+            const uint32_t bb = (uint32_t)b | (sign << 31);
+            float fx;
+            std::memcpy(&fx, &bb, 4);
+            const double a = (double)fx - 0.25;
+            const double ref = a / (double)n;
+            const double q0 = a * y;
+            const double e = std::fma(-q0, (double)n, a);
+            const double q = std::fma(e, y, q0);
+            if (std::memcmp(&ref, &q, 8)) dd++;
+            const float h1 = (float)(ref - 0.5), h2 = (float)(q - 0.5);
+            if (std::memcmp(&h1, &h2, 4)) df++;
+        }
+    }
+    *float_diff = df;
+    *double_diff = dd;
 }
 
 void orc_quantize(const float *frame, uint64_t npix, unsigned char *rgba8, float *depth) {

@@ -83,6 +83,8 @@ int orc_max_threads(void);
  * count of floats in a bit-pattern range on which that restatement differs from the host's libm */
 void orc_trig(const float *x, uint32_t n, float *cos_out, float *sin_out);
 void orc_trig_compare_libm(uint32_t lo_bits, uint32_t hi_bits, uint64_t *cos_diff, uint64_t *sin_diff);
+/* check of the kernels' three-operation division by the image size against the IEEE division (see vmx_oracle.cpp) */
+void orc_check_div_by_count(uint32_t n, uint32_t lo_bits, uint32_t hi_bits, uint64_t *float_diff, uint64_t *double_diff);
 /* Camera::saveFrame conversion (camera.cpp:159-163) */
 void orc_quantize(const float *frame, uint64_t npix, unsigned char *rgba8, float *depth);
 

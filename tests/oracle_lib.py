@@ -67,6 +67,7 @@ def lib(fast=False):
     l.orc_quantize.argtypes = [P, C.c_uint64, P, P]
     l.orc_trig.argtypes = [P, C.c_uint32, P, P]
     l.orc_trig_compare_libm.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    l.orc_check_div_by_count.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     _libs[name] = l
     return l
 
@@ -183,7 +184,12 @@ class OracleScene:
         return out, st.as_dict()
 
     def render(self, cam, opts, rng_mode=ORC_RNG_XOSHIRO_KEYED, threads=0):
+        """PathTracer::Render restated.  opts.world > 1: only this rank's stripes (vmx_render's sharding), packed in
+        ascending row order [local_rows, W, 5] — a pixel subset of the same frame (streams are keyed by the global pixel)"""
         W, H = cam.image_res[0], cam.image_res[1]
+        if opts.world > 1:
+            stripe = opts.stripe_rows or 16
+            H = sum(1 for y in range(H) if (y // stripe) % opts.world == opts.rank)
         out = np.empty((H, W, 5), np.float32)
         st = L.Stats()
         self.l.orc_render(self.h, C.byref(cam), C.byref(opts), rng_mode, threads, out.ctypes.data, C.byref(st))

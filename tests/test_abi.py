@@ -31,17 +31,19 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for name in fns:
         assert hasattr(hip_lib, name), f"{name} declared in the header but not exported"
     assert sorted(L.SYMBOLS) == fns, "ctypes binding and header disagree on the function list"
-    assert hip_lib.vmx_abi_version() == 1
+    assert hip_lib.vmx_abi_version() == 2
 
 
 def test_struct_layouts_match_header(tmp_path):
     names = {"vmx_sphere": L.Sphere, "vmx_camera": L.CameraDesc, "vmx_opts": L.Opts, "vmx_stage_stats": L.StageStats,
-             "vmx_stats": L.Stats, "vmx_scene_desc": L.SceneDesc, "vmx_rayhit": L.RayHit, "vmx_timings": L.Timings}
+             "vmx_stats": L.Stats, "vmx_scene_desc": L.SceneDesc, "vmx_rayhit": L.RayHit, "vmx_timings": L.Timings,
+             "vmx_multi_times": L.MultiTimes}
     prog = '#include <stdio.h>\n#include <stddef.h>\n#include "vermilion_hip.h"\nint main(void){\n'
     for n in names:
         prog += f'printf("{n} %zu\\n", sizeof({n}));\n'
     prog += 'printf("off_seed %zu\\n", offsetof(vmx_opts, seed));\n'
     prog += 'printf("off_primary %zu\\n", offsetof(vmx_stats, primary));\n'
+    prog += 'printf("off_units %zu\\n", offsetof(vmx_camera, rotation_units));\n'
     prog += 'printf("off_flags %zu\\n", offsetof(vmx_rayhit, flags));\nreturn 0;}\n'
     src = tmp_path / "sz.c"
     src.write_text(prog)
@@ -53,6 +55,7 @@ def test_struct_layouts_match_header(tmp_path):
     assert int(out["off_seed"]) == L.Opts.seed.offset
     assert int(out["off_primary"]) == L.Stats.primary.offset
     assert int(out["off_flags"]) == L.RayHit.flags.offset
+    assert int(out["off_units"]) == L.CameraDesc.rotation_units.offset
     assert C.sizeof(L.RayHit) == 64 and C.sizeof(L.Sphere) == 48
     src = open(HEADER).read()
     assert len(L.K_NAMES) == int(re.search(r"#define VMX_K_COUNT (\d+)", src).group(1))

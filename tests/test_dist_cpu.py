@@ -34,7 +34,11 @@ def _worker(rank, world, port, W, H, R, q):
         rows = torch.as_tensor(va.local_row_indices(H, R, rank, world))
         local = frame[rows].contiguous()
         assert local.shape[0] == va.local_rows(H, R, rank, world)
-        out = vdist.gather_frame(local, W, H, R, rank, world, dst=0)
+        times = vdist.ExchangeTimes()
+        out = vdist.gather_frame(local, W, H, R, rank, world, dst=0, times=times)
+        # the exchange is timed apart from the rendering on every rank; only the root de-interleaves
+        assert len(times.pairs["gather"]) == 1 and times.ms("gather") >= 0.0
+        assert len(times.pairs["assemble"]) == (1 if rank == 0 else 0)
         if rank == 0:
             q.put(bool(torch.equal(out, frame)))
         else:

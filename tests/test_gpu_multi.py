@@ -45,6 +45,15 @@ def test_multi_render_equals_single_device_frame_and_the_oracle(world, stripe):
             eimg, est = multi.render(cam, eopts)
             assert np.array_equal(bits(eimg), bits(oimg)) and est["samples"] == ost["samples"]
             assert est["rays_primary"] + est["rays_secondary"] < 0.5 * (ost["rays_primary"] + ost["rays_secondary"])
+        # the exchange step timed apart from the rendering (vmx_multi_timings; SURVEY 8e: "gather time separately")
+        tm = multi.timings()
+        assert tm["world"] == world and len(tm["render_ms"]) == len(tm["copy_ms"]) == world
+        for r in range(world):  # (a rank without rows — 7 stripes over 8 ranks — renders and copies nothing)
+            has_rows = va.local_rows(H, stripe, r, world) > 0
+            assert (tm["render_ms"][r] > 0) == has_rows and (tm["copy_ms"][r] > 0) == has_rows
+        assert tm["slowest_render_ms"] == max(tm["render_ms"]) and tm["gather_ms"] == max(tm["copy_ms"])
+        assert abs(tm["gather_sum_ms"] - sum(tm["copy_ms"])) < 1e-9 and tm["assemble_ms"] > 0
+        assert tm["wall_ms"] >= tm["slowest_render_ms"] and tm["wall_ms"] >= tm["assemble_ms"]
         # BruteForceTracer through the same sharding
         bf, _ = multi.render_bruteforce(cam, va.make_opts(seed=4, stripe_rows=stripe))
         bref, _ = osc.render_bruteforce(cam, va.make_opts(seed=4))

@@ -122,6 +122,26 @@ def test_device_cosf_sinf_bit_exact():
 #                                       still finish in the fused tail
 #   pipeline=4, tail_threshold=1        ... and every bounce generation through k_trace_w<1> + k_shade<1>
 # so the last two rows put BOTH production traversal kernels of the bench frame directly against the oracle.
+def test_camera_in_radians_bit_exact(pair):
+    """VMX_ROTATION_RADIANS (what the adapter passes: Camera::mRotation as it stands, camera.cpp:43-47 /
+    pathtracer.cpp:219-221): arbitrary radians — not the image of any float degree value — give the oracle's frame"""
+    c = pair.camf()
+    rad = np.float32([0.1234567, -1.7654321, 0.0543219]) if pair.name == "sponza260k" else np.float32([0.0371, 0.0123, -0.2001])
+    cam = va.make_camera(c["position"], None, 96, 64, 16, rotation_rad=rad)
+    opts = va.make_opts(seed=3, early_stop=True)
+    img, st = pair.gpu.render(cam, opts)
+    ref, rst = pair.cpu.render(cam, opts)
+    assert np.array_equal(bits(img), bits(ref)) and st["samples"] == rst["samples"]
+    tri, t = pair.gpu.primary_ids(cam, opts, 2)
+    o, d = O.primary_rays(cam, opts, 2)
+    rtri, rt = pair.cpu.trace(o, d)
+    assert np.array_equal(tri, rtri) and np.array_equal(bits(t), bits(rt))
+    bad = va.make_camera(c["position"], None, 96, 64, 16, rotation_rad=rad)
+    bad.rotation_units = 7
+    with pytest.raises(va.VmxError):
+        pair.gpu.render(bad, opts)
+
+
 PRODUCTION_FORMS = [{}, {"pipeline": 4}, {"pipeline": 4, "tail_threshold": 1}]
 FORM_IDS = ["default", "split", "split-notail"]
 

@@ -158,6 +158,58 @@ def test_config4_full_frame_256spp(sponza):
         assert np.array_equal(bits(parts[r]), bits(e[va.local_row_indices(H, 16, r, 2)]))
 
 
+def _against_the_oracle_rows(sc, osc, cam, seed, rank, world, stripe, H):
+    """whole full-size frames of the HIP path against the oracle on the pixel subset the oracle can do in seconds: the
+    rows of rank `rank` of `world` (stripes of `stripe` rows spread over the whole image height)"""
+    rows = va.local_row_indices(H, stripe, rank, world)
+    ELIDE = va.VMX_SAMPLING_PARITY | va.VMX_SAMPLING_ELIDE_DEAD
+    sub = dict(rank=rank, world=world, stripe_rows=stripe)
+    # fixed count: the bench's own frame (default: the traversal kernels sort their finished rays), the frame with every
+    # Radiance step shaded in full (bench.py's headline form), the two-phase form, and VMX_SAMPLING_ELIDE_DEAD
+    ref, ost = osc.render(cam, va.make_opts(seed=seed, early_stop=False, **sub))
+    assert ref.shape[0] == len(rows)
+    for kw in (dict(), dict(pipeline=0x100), dict(pipeline=0x200), dict(sampling=ELIDE)):
+        img, st = sc.render(cam, va.make_opts(seed=seed, early_stop=False, **kw))
+        assert np.array_equal(bits(img[rows]), bits(ref)), kw
+        # the same rows rendered as a rank of their own: identical again, and the counters are the oracle's
+        part, sp = sc.render(cam, va.make_opts(seed=seed, early_stop=False, **sub, **kw))
+        assert np.array_equal(bits(part), bits(ref)), kw
+        assert sp["samples"] == ost["samples"]
+        if "sampling" not in kw:  # (under ELIDE_DEAD only the traced rays are counted)
+            assert sp["rays_primary"] == ost["rays_primary"] and sp["rays_secondary"] == ost["rays_secondary"], kw
+            assert sp["primary"]["tri_hits"] + sp["bounce"]["tri_hits"] == ost["primary"]["tri_hits"], kw
+            assert sp["primary"]["continued"] + sp["bounce"]["continued"] == ost["primary"]["continued"], kw
+    # early stop on (what the adapter renders), default and elided
+    ref, ost = osc.render(cam, va.make_opts(seed=seed, early_stop=True, **sub))
+    for kw in (dict(), dict(sampling=ELIDE)):
+        img, st = sc.render(cam, va.make_opts(seed=seed, early_stop=True, **kw))
+        assert np.array_equal(bits(img[rows]), bits(ref)), kw
+        part, sp = sc.render(cam, va.make_opts(seed=seed, early_stop=True, **sub, **kw))
+        assert np.array_equal(bits(part), bits(ref)) and sp["samples"] == ost["samples"] == int(ref[:, :, 4].astype(np.int64).sum())
+        if "sampling" not in kw:
+            assert sp["rays_primary"] == ost["rays_primary"] + sp["samples_discarded"]
+
+
+def test_config4_bench_frame_against_the_oracle(sponza):
+    """BASELINE config 4 at full size and full spp, seed 1 — the frame bench.py times — put against the oracle itself
+    (pathtracer.cpp:200-328 restated) on one sixteenth of its rows: the default form, the headline form, the two-phase
+    form, VMX_SAMPLING_ELIDE_DEAD and the early-stop frames, bit for bit, with ray / sample / hit / continuation
+    counters (the one link that was self-comparison only)"""
+    W, H, spp = 1920, 1080, 256
+    osc = O.OracleScene(*scenes.sponza260k())
+    _against_the_oracle_rows(sponza, osc, sponza_cam(W, H, spp), 1, 5, 16, 4, H)
+
+
+def test_config3_bunny_frame_against_the_oracle():
+    """BASELINE config 3 (bunny stand-in, 1024 x 1024 x 128 spp) at full size against the oracle on a sixteenth of its rows"""
+    sc = va.Scene(*scenes.bunny70k())
+    osc = O.OracleScene(*scenes.bunny70k())
+    c = scenes.SCENES["bunny70k"][1]()
+    cam = va.make_camera(c["position"], c["rotation_deg"], 1024, 1024, 128)
+    _against_the_oracle_rows(sc, osc, cam, 9, 11, 16, 4, 1024)
+    sc.close()
+
+
 def test_config3_bunny_1024_128spp():
     """BASELINE config 3 at full size: split wavefront and fused kernel agree (the first-generation kernels:
     test_first_generation_kernels_give_the_same_frames)"""
@@ -256,6 +308,32 @@ def test_first_generation_kernels_give_the_same_frames(sponza):
         sponza.render(cam, va.make_opts(seed=1, pipeline=2))
     with pytest.raises(va.VmxError, match="A/B library"):
         sponza.render(cam, va.make_opts(seed=1, early_stop=False, reorder=0x35, tail_threshold=1))
+
+
+@pytest.mark.skipif(not os.path.exists(AB_LIB), reason="build/libvermilion_hip_ab.so not built (make -C vermilion_amd/csrc ab)")
+def test_phase_pure_pool_probe_gives_the_same_frames(sponza):
+    """VERDICT r3 item 1's probe (vmx_trace_pool.inc, A/B library only; vmx_opts.reserved[0] bit 10): a bounce traversal
+    whose waves hold one phase, ray state in LDS by slot.  Per-ray test order is the reference's (bvh.cpp:47-145), so
+    frames and ray counts equal the product's bit for bit — with every bounce generation through it (tail_threshold=1),
+    with deep stacks in LDS and with most levels in the HBM slab, and with a pool barely larger than the block."""
+    ab = va._lib.load(AB_LIB)
+    pos, nrm, uv = scenes.sponza260k()
+    cam = sponza_cam(960, 540, 64)
+    a, sa = sponza.render(cam, va.make_opts(seed=2, early_stop=False, pipeline=4 | 0x100, tail_threshold=1))
+    with va.Scene(pos, nrm, uv, lib=ab) as old:
+        for env in (dict(), dict(VMX_AB_POOL_SLOTS="320", VMX_AB_POOL_LEVELS="3"), dict(VMX_AB_POOL_SLOTS="704", VMX_AB_POOL_LEVELS="12")):
+            for k in ("VMX_AB_POOL_SLOTS", "VMX_AB_POOL_LEVELS"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            try:
+                b, sb = old.render(cam, va.make_opts(seed=2, early_stop=False, pipeline=4 | 0x100 | 0x400, tail_threshold=1))
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            assert np.array_equal(bits(a), bits(b)), env
+            assert sb["rays_secondary"] == sa["rays_secondary"] and sb["bounce"]["tri_hits"] == sa["bounce"]["tri_hits"]
+    with pytest.raises(va.VmxError, match="A/B library"):
+        sponza.render(cam, va.make_opts(seed=2, early_stop=False, pipeline=0x100 | 0x400))
 
 
 def test_two_phase_shading_equals_one_phase(sponza):

@@ -118,3 +118,31 @@ def test_octant_tables_near_plane_product_is_the_slab_minimum():
         far = (np.where(neg, lo, hi) * inv).astype(f32)
     ok = ~(np.isnan(t0) | np.isnan(t1))  # inf * 0: such rays take the exact path in the kernels
     assert np.all((np.minimum(t0, t1) == near)[ok]) and np.all((np.maximum(t0, t1) == far)[ok])
+
+
+def test_division_by_the_image_size_with_a_reciprocal_and_one_fma_is_the_ieee_division():
+    """vmx_kernels.hip: div_by_count — pathtracer.cpp:251-252 divide the sample's film coordinate by the image size in
+    double; the kernels multiply by the host's RN(1 / n) and correct once with an FMA (Markstein), which the comment
+    there proves equal to the IEEE quotient for every finite numerator.  Here exhaustively: EVERY float a camera ray
+    can produce as its coordinate (|fx| up to just past the image size, both signs, the tiny ones included) for the
+    image sizes of BASELINE.json's configs and of the tests, and every float at all for a few awkward divisors."""
+    import ctypes as C
+    import struct
+    import oracle_lib as O
+    lib = O.lib(fast=False)
+
+    def bits(x):
+        return struct.unpack("<I", struct.pack("<f", x))[0]
+    total = 0
+    for n in (1920, 1080, 3840, 2160, 1024, 512, 256, 640, 360, 160, 110, 96, 64, 33, 17, 1, 3, 7):
+        fd, dd = C.c_uint64(1), C.c_uint64(1)
+        hi = bits(float(n) + 2.0)
+        lib.orc_check_div_by_count(n, 0, hi, C.byref(fd), C.byref(dd))
+        assert fd.value == 0 and dd.value == 0, (n, fd.value, dd.value)
+        total += 2 * (hi + 1)
+    for n in (0xFFFFFFFF, 4294967291, 16777217, 6700417):  # every finite float
+        fd, dd = C.c_uint64(1), C.c_uint64(1)
+        lib.orc_check_div_by_count(n, 0, 0x7F7FFFFF, C.byref(fd), C.byref(dd))
+        assert fd.value == 0 and dd.value == 0, (n, fd.value, dd.value)
+        total += 2 * 0x7F800000
+    assert total > 1.7e10

@@ -147,6 +147,35 @@ def test_camera_matrix_and_forward_axis():
     assert np.allclose(M, Ry @ Rx @ Rz, atol=2e-6)
 
 
+def test_camera_rotation_in_radians_is_taken_as_it_stands():
+    """VMX_ROTATION_RADIANS: the adapter holds Camera::mRotation (radians, x and y negated, camera.cpp:43-47) and hands it
+    over unchanged; pathtracer.cpp:219-221 rotates by exactly those three floats"""
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        deg = np.float32(rng.uniform(-180, 180, 3)).astype(np.float64)  # cameraSettings.rotation is float (types.h)
+        # what the Camera ctor computes from the settings' degrees, in double, narrowed to float
+        rad = np.float32([-deg[0] * 3.1415926535 / 180, -deg[1] * 3.1415926535 / 180, deg[2] * 3.1415926535 / 180])
+        a = O.camera_matrix(va.make_camera((0, 0, 0), np.float32(deg), 8, 8, 4))
+        b = O.camera_matrix(va.make_camera((0, 0, 0), None, 8, 8, 4, rotation_rad=rad))
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # arbitrary radians (a host that wrote the public field): the matrix of exactly those angles, no degree round trip
+    for _ in range(200):
+        r = np.float32(rng.uniform(-7, 7, 3))
+        a, b, c = (float(x) for x in r)
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+        M = O.camera_matrix(va.make_camera((0, 0, 0), None, 8, 8, 4, rotation_rad=r)).T
+        assert np.allclose(M, Ry @ Rx @ Rz, atol=3e-6)
+    # a one-ulp change of an angle is a different camera (what the degree round trip used to do to 9 % of them)
+    r = np.float32([0.3, 1.1, -0.7])
+    r2 = r.copy()
+    r2[1] = np.nextafter(r2[1], np.float32(4))
+    m1 = O.camera_matrix(va.make_camera((0, 0, 0), None, 8, 8, 4, rotation_rad=r))
+    m2 = O.camera_matrix(va.make_camera((0, 0, 0), None, 8, 8, 4, rotation_rad=r2))
+    assert not np.array_equal(m1.view(np.uint32), m2.view(np.uint32))
+
+
 def test_pixel_footprint_and_film_geometry():
     """jitter footprint [-0.75, 0.25) around the integer pixel coordinate"""
     W, H = 16, 8
@@ -169,12 +198,65 @@ def test_rng_stream():
     st = C.c_uint64(1234567)
     got = [O.lib().orc_splitmix64(C.byref(st)) for _ in range(3)]
     assert got == [6457827717110365317, 3203168211198807973, 9817491932198370423]
+    # known answers of the keyed stream (seed, pixel, sample), from an independent restatement in Python integers of the
+    # definition in oracle/vmx_oracle.cpp: Xoshiro::init / vmx_kernels.hip: rng_pixel_key + rng_init_keyed (round 4: two
+    # mix64 per pixel, three 64-bit multiplies per sample) followed by xoshiro256**
+    M = (1 << 64) - 1
+
+    def mix64(z):
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    def rotl(x, k):
+        return ((x << k) | (x >> (64 - k))) & M
+
+    def keyed(seed, pixel, k, n):
+        a = mix64(seed ^ ((pixel << 32) & M))
+        b = mix64((a + 0x9E3779B97F4A7C15) & M)
+        s0 = mix64((a + k) & M)
+        t = ((s0 ^ b) * 0xD6E8FEB86659FD93) & M
+        s1 = t ^ (t >> 32)
+        s = [s0, s1, rotl(s0, 24) ^ b, rotl(s1, 37) ^ a]
+        out = []
+        for _ in range(n):
+            out.append((rotl((s[1] * 5) & M, 7) * 9) & M)
+            t = (s[1] << 17) & M
+            s[2] ^= s[0]
+            s[3] ^= s[1]
+            s[1] ^= s[2]
+            s[0] ^= s[3]
+            s[2] ^= t
+            s[3] = rotl(s[3], 45)
+        return out
+    assert O.stream(1, 2, 3, 2).tolist() == [10614261844916165048, 15287749866284423084]
+    assert O.stream(0, 0, 0, 2).tolist() == [675374820455444685, 3476903706756334224]
+    for key in ((1, 2, 3), (12345678901234567, 2073599, 255), (7, 1 << 31, 4000000000), (M, 0xFFFFFFFF, 0xFFFFFFFF)):
+        assert O.stream(*key, 8).tolist() == keyed(*key, 8), key
     a = O.stream(1, 2, 3, 64)
     assert np.array_equal(a, O.stream(1, 2, 3, 64)) and len(set(a.tolist())) == 64
     assert not np.array_equal(a, O.stream(1, 2, 4, 64)) and not np.array_equal(a, O.stream(1, 3, 3, 64))
     big = np.concatenate([O.stream(9, p, 0, 256) for p in range(64)])
     u = (big >> np.uint64(11)).astype(np.float64) * 2.0**-53
     assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.005
+    # neighbouring streams — consecutive samples of a pixel, the same sample of consecutive pixels, consecutive seeds —
+    # are unrelated: every bit of the first outputs flips with probability 1/2 from one stream to the next, and the
+    # first draws of 2^16 streams are uniform and serially uncorrelated (the jitters of a frame ARE such first draws)
+    for streams in ([O.stream(5, 77, k, 4) for k in range(4096)], [O.stream(5, p, 11, 4) for p in range(4096)],
+                    [O.stream(s_, 3, 2, 4) for s_ in range(4096)]):
+        x = np.stack(streams)                                   # [stream, draw]
+        flips = x[1:] ^ x[:-1]
+        for d in range(4):
+            f = np.unpackbits(flips[:, d].copy().view(np.uint8).reshape(-1, 8), axis=1).mean()
+            assert abs(f - 0.5) < 0.004, (d, f)
+        per_bit = np.unpackbits(flips[:, 0].copy().view(np.uint8).reshape(-1, 8), axis=1).mean(axis=0)
+        assert np.all(np.abs(per_bit - 0.5) < 0.04)            # 4095 trials per bit: 5 sigma = 0.039
+    first = np.concatenate([O.stream(2, p, k, 1) for p in range(256) for k in range(256)])
+    u = (first >> np.uint64(11)).astype(np.float64) * 2.0**-53
+    assert abs(u.mean() - 0.5) < 0.006 and abs(u.var() - 1 / 12) < 0.003
+    assert abs(np.corrcoef(u[1:], u[:-1])[0, 1]) < 0.02 and abs(np.corrcoef(u[256:], u[:-256])[0, 1]) < 0.02
+    h, _ = np.histogram(u, bins=64, range=(0, 1))
+    assert ((h - 1024.0) ** 2 / 1024.0).sum() < 130             # chi-square, 63 degrees of freedom (p ~ 1e-6 at 130)
 
 
 def test_early_stop_off_takes_every_sample_and_spp_rounds_down(cornell):

@@ -17,11 +17,14 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = [  # (vmx_timings name, substring of the demangled kernel name) — the kernels of the default (sorted) frame
-    ("raygen", "k_raygen<0>"), ("trace_camera", "k_trace_w<0, false, true>"), ("shade_camera", "k_shade<0, false, false, 2>"),
-    ("trace_bounce", "k_trace_w<1, false, true>"), ("shade_bounce", "k_shade<1, false, false, 2>"),
+# (vmx_timings name, substring of the demangled kernel name) — the kernels of the bench's headline frame: every Radiance
+# step shaded in full (vmx_opts.reserved[0] bit 8, bench.py HEADLINE_FORM)
+CLASSES = [
+    ("raygen", "k_raygen<0>"), ("trace_camera", "k_trace_w<0, false, false>"), ("shade_camera", "k_shade<0, false, false, 0>"),
+    ("trace_bounce", "k_trace_w<1, false, false>"), ("shade_bounce", "k_shade<1, false, false, 0>"),
     ("tail", "k_paths<false, 2"), ("fused", "k_paths<false, 0"), ("resolve", "k_resolve"),
 ]
+HEADLINE_FORM = 0x100
 N_SIMD, N_CU, NOMINAL_HZ = 1024, 256, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz max clock
 
 
@@ -85,8 +88,9 @@ def main():
         k["derived"] = d
         kernels[name] = k
     out = {
-        "round": 3,
+        "round": 4,
         "tag": tag,
+        "form": HEADLINE_FORM,
         "workload": workload,
         "command": "rocprofv3 --kernel-trace --pmc <one group per pass> --output-format csv -- python3 bench.py "
                    f"--steps 2 --warmup 1 --no-cpu-baseline --no-extras  (tools/pmc.sh TAG={tag}; this file: tools/make_counters.py)",

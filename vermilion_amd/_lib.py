@@ -27,6 +27,8 @@ VMX_BVH_SAH = 1
 VMX_BVH_LBVH = 2
 VMX_BVH_PLOC = 3
 VMX_BF_ABS_INT = 1
+VMX_ROTATION_DEGREES = 0
+VMX_ROTATION_RADIANS = 1
 
 
 class Sphere(C.Structure):
@@ -48,6 +50,8 @@ class CameraDesc(C.Structure):
         ("back_size", C.c_float * 2),
         ("image_res", C.c_uint32 * 2),
         ("rays_per_pixel", C.c_uint32),
+        ("rotation_units", C.c_uint32),
+        ("rotation_rad", C.c_float * 3),
     ]
 
 
@@ -131,6 +135,11 @@ class Timings(C.Structure):
                 for i, n in enumerate(K_NAMES)}
 
 
+class MultiTimes(C.Structure):
+    _fields_ = [("slowest_render_ms", C.c_double), ("gather_ms", C.c_double), ("gather_sum_ms", C.c_double),
+                ("assemble_ms", C.c_double), ("wall_ms", C.c_double), ("world", C.c_uint32), ("pad", C.c_uint32)]
+
+
 class RayHit(C.Structure):
     _fields_ = [
         ("location", C.c_float * 3),
@@ -176,6 +185,7 @@ SYMBOLS = {
     "vmx_multi_destroy": (C.c_int, [_P]),
     "vmx_multi_world": (C.c_uint32, [_P]),
     "vmx_multi_routes": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vmx_multi_timings": (C.c_int, [_P, C.POINTER(MultiTimes), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vmx_multi_bind_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vmx_multi_render": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),
     "vmx_multi_render_device": (C.c_int, [_P, C.POINTER(CameraDesc), C.POINTER(Opts), _P, C.POINTER(Stats)]),

@@ -24,26 +24,9 @@ bool HipIntegratorBase::upload(MeshEngine *mEng) {
     if ((mScene || mMulti) && mUploadedFrom == mEng && mUploadedFaces == faces &&
         mUploadedTextures == mEng->boundTextures.size())
         return true;
-    pos.reserve(faces * 9), nrm.reserve(faces * 9), uv.reserve(faces * 6);
-    float lastUv[6] = {0, 0, 0, 0, 0, 0};
-    for (aiMesh *mesh : mEng->sceneMeshes) {
-        // createBVH declares `glm::vec2 v0uv, v1uv, v2uv;` per mesh (meshEngine.cpp:663-667) and assigns them only
-        // when the mesh has UVs.  What a mesh WITHOUT UVs gets is undefined in the reference — it depends on the
-        // GLM the submodule resolves to (kUvOfMeshesWithoutUvs, HipPathTracer.h)
-        if (kUvOfMeshesWithoutUvs == UvRule::Zero) std::memset(lastUv, 0, sizeof(lastUv));
-        for (unsigned f = 0; f < mesh->mNumFaces; ++f) {
-            for (int c = 0; c < 3; ++c) {
-                const unsigned i = mesh->mFaces[f].mIndices[c];
-                pos.push_back(mesh->mVertices[i].x), pos.push_back(mesh->mVertices[i].y), pos.push_back(mesh->mVertices[i].z);
-                nrm.push_back(mesh->mNormals[i].x), nrm.push_back(mesh->mNormals[i].y), nrm.push_back(mesh->mNormals[i].z);
-                if (mesh->HasTextureCoords(0)) {
-                    lastUv[c * 2] = mesh->mTextureCoords[0][i].x;
-                    lastUv[c * 2 + 1] = mesh->mTextureCoords[0][i].y;
-                }
-            }
-            uv.insert(uv.end(), lastUv, lastUv + 6);
-        }
-    }
+    // the walk itself is a template over the mesh type (flatten.h) so that it also runs in this repository's CPU
+    // tests with a plain stand-in mesh: mesh-major, face-minor, the face's three indices, kUvOfMeshesWithoutUvs
+    flattenMeshes(mEng->sceneMeshes, kUvOfMeshesWithoutUvs, pos, nrm, uv);
     vmx_scene_destroy(mScene);
     vmx_multi_destroy(mMulti);
     mScene = nullptr, mMulti = nullptr;
@@ -82,10 +65,11 @@ vmx_camera HipIntegratorBase::describe(const Camera *cam) {
     vmx_camera c;
     std::memset(&c, 0, sizeof(c));
     c.position[0] = cam->mPosition.x, c.position[1] = cam->mPosition.y, c.position[2] = cam->mPosition.z;
-    // Camera stores radians with x,y negated (camera.cpp:43-47); the ABI takes cameraSettings' degrees
-    c.rotation_deg[0] = (float)(-cam->mRotation.x * 180 / 3.1415926535);
-    c.rotation_deg[1] = (float)(-cam->mRotation.y * 180 / 3.1415926535);
-    c.rotation_deg[2] = (float)(cam->mRotation.z * 180 / 3.1415926535);
+    // Camera::mRotation is what PathTracer::Render hands to glm::rotate (pathtracer.cpp:219-221): radians, x and y
+    // already negated by the ctor (camera.cpp:43-47) — or whatever a host wrote into the public field.  Passed through
+    // as it stands (a detour through degrees moved 9 % of arbitrary radians by one ulp)
+    c.rotation_units = VMX_ROTATION_RADIANS;
+    c.rotation_rad[0] = cam->mRotation.x, c.rotation_rad[1] = cam->mRotation.y, c.rotation_rad[2] = cam->mRotation.z;
     c.back_distance = cam->mDistToFilm;
     c.back_size[0] = cam->sensorSizeX, c.back_size[1] = cam->sensorSizeY;
     c.image_res[0] = cam->uImageU, c.image_res[1] = cam->uImageV;

@@ -18,19 +18,11 @@
 #include <utility>
 #include <vector>
 
+#include "flatten.h"                  // flattenMeshes, UvRule / kUvOfMeshesWithoutUvs
 #include "integrators/integrators.h"  // Vermilion::Integrator, Camera, MeshEngine
 #include "vermilion_hip.h"
 
 namespace Vermilion {
-
-// UVs of a mesh WITHOUT texture coordinates.  MeshEngine::createBVH (meshEngine.cpp:663-667) declares
-// `glm::vec2 v0uv, v1uv, v2uv;` inside its per-mesh loop and assigns them only under HasTextureCoords(0), so for such a
-// mesh the reference passes default-constructed vec2s to Triangle — and what those hold is the GLM version's choice:
-// zeros with GLM <= 0.9.8 (or GLM_FORCE_CTOR_INIT), indeterminate with GLM 0.9.9's default (in practice the stack
-// slots still hold the previous mesh's last face).  extern/glm is an unpinned submodule (.gitmodules:7-9): neither
-// reading can be pinned.  It matters only for mixed UV / no-UV scenes with a bound texture.  One switch:
-enum class UvRule { Zero, CarryOverFromPreviousMesh };
-constexpr UvRule kUvOfMeshesWithoutUvs = UvRule::Zero;
 
 // what both adapters share: the device copy of MeshEngine's triangles / textures, the camera marshalling
 // and the pixel write-back through Camera::setPixelValue
@@ -70,14 +62,14 @@ class HipPathTracer : public HipIntegratorBase {
     explicit HipPathTracer(uint64_t seed = 1, int device = 0) : HipIntegratorBase(seed, {device}) {}
     HipPathTracer(uint64_t seed, std::vector<int> devices) : HipIntegratorBase(seed, std::move(devices)) {}
     void Render(std::vector<Vermilion::Camera *> &cameraList, MeshEngine *mEng) override;
-    // vmx_opts.sampling of the frames.  Default: the reference's sampling with VMX_SAMPLING_ELIDE_DEAD — all Render
-    // leaves behind is Camera::mImage (r, g, b, sample count), which that flag keeps bit for bit while the frame takes a
-    // third of the time; uRaysFired then counts the rays that were traced.  setSampling(VMX_SAMPLING_PARITY) traces
-    // every ray the reference traces.
+    // vmx_opts.sampling of the frames.  Default: VMX_SAMPLING_PARITY — every ray the reference traces is traced, and
+    // Camera::uRaysFired counts them.  setSampling(VMX_SAMPLING_PARITY | VMX_SAMPLING_ELIDE_DEAD) is the opt-in the
+    // header describes: all Render leaves behind is Camera::mImage (r, g, b, sample count), which that flag keeps bit
+    // for bit while the frame takes half the time; uRaysFired then counts only the rays that were traced (~22 %).
     void setSampling(uint32_t sampling) { mSampling = sampling; }
 
    private:
-    uint32_t mSampling = VMX_SAMPLING_PARITY | VMX_SAMPLING_ELIDE_DEAD;
+    uint32_t mSampling = VMX_SAMPLING_PARITY;
 };
 
 // Replaces Vermilion::BruteForceTracer (core/integrators/integrators.h:18-21,

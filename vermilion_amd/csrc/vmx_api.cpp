@@ -134,6 +134,7 @@ struct Workspace {
     size_t full_words = 0, full_tmp_bytes = 0;
     DevBuf<unsigned char> out_rec;   // k_trace_w<.., SORT>: 32-byte records of the camera rays that still need shading
     DevBuf<unsigned int> out_count;
+    size_t out_capacity = 0;         // entries out_rec was sized for
     DevBuf<unsigned char> accum;        // float4 per local pixel
     DevBuf<unsigned int> count, cursor, active[2], next_count;
     DevBuf<DevCounters> counters;
@@ -230,9 +231,13 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
                     "rays_per_pixel < 4 renders no sample (uSamplesPerPixel/4 == 0, pathtracer.cpp:247)");
     if ((o.sampling & VMX_SAMPLING_MODE_MASK) > VMX_SAMPLING_CORRECTED || (o.sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE | VMX_SAMPLING_ELIDE_DEAD)))
         return fail(VMX_ERR_INVALID, "unknown sampling mode");
-    const float rx = (float)(-cam.rotation_deg[0] * 3.1415926535 / 180);
-    const float ry = (float)(-cam.rotation_deg[1] * 3.1415926535 / 180);
-    const float rz = (float)(cam.rotation_deg[2] * 3.1415926535 / 180);
+    if (cam.rotation_units > VMX_ROTATION_RADIANS) return fail(VMX_ERR_INVALID, "unknown rotation_units");
+    // Camera ctor (camera.cpp:43-47): mRotation = (-rx, -ry, +rz) * 3.1415926535 / 180, double arithmetic narrowed to
+    // float; with VMX_ROTATION_RADIANS the caller hands over mRotation itself
+    const bool rad = cam.rotation_units == VMX_ROTATION_RADIANS;
+    const float rx = rad ? cam.rotation_rad[0] : (float)(-cam.rotation_deg[0] * 3.1415926535 / 180);
+    const float ry = rad ? cam.rotation_rad[1] : (float)(-cam.rotation_deg[1] * 3.1415926535 / 180);
+    const float rz = rad ? cam.rotation_rad[2] : (float)(cam.rotation_deg[2] * 3.1415926535 / 180);
     M3 m = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
     m = rotate_axis(m, ry, 0, 1, 0);
     m = rotate_axis(m, rx, 1, 0, 0);
@@ -243,6 +248,7 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
     fr.film_dist = cam.back_distance;
     fr.sensor_x = cam.back_size[0], fr.sensor_y = cam.back_size[1];
     fr.width = W, fr.height = H;
+    fr.inv_width = 1.0 / (double)W, fr.inv_height = 1.0 / (double)H;
     fr.spp = spp, fr.quarter = spp / 4, fr.kmax = 4 * (spp / 4);
     fr.nmin = (uint32_t)std::floor(std::sqrt((double)spp));
     fr.early_stop = o.early_stop ? 1u : 0u;
@@ -306,7 +312,9 @@ int read_counts(vmx_scene *sc, unsigned int *d_counts, hipStream_t s, uint64_t &
     HIP_TRY(hipStreamSynchronize(s));
     total = 0, largest = 0;
     for (uint32_t q = 0; q < kSubQueues; ++q) {
-        const uint32_t c = std::min(h[q * 32], sub_capacity);  // an overflowing append leaves the tail high
+        // an append that would have written past its sub-list wrote nothing and left the tail high (id_append)
+        if (h[q * 32] > sub_capacity) return fail(VMX_ERR_NOMEM, "live-path list overflow (sub-list " + std::to_string(q) + ")");
+        const uint32_t c = h[q * 32];
         total += c;
         largest = std::max(largest, c);
         if (per_queue) per_queue[q] = c;
@@ -352,6 +360,8 @@ struct Tuning {
     uint32_t sort_mode;  // bounce reordering: obits | dbits << 4 | dir_major << 8 | chunk_log2 << 12 | shade_sorted << 20
     bool two_phase;      // split passes of vmx_render: k_shade_ends + k_shade on what it queues (render_impl)
     bool sorted;         // ... and the camera rays sorted by the trace kernel itself (k_trace_w<0, .., SORT>): no k_shade_ends
+    bool pool;           // A/B library, reserved[0] bit 10: the bounce generations of a pass through k_trace_pool (phase-pure
+                         // steps, ray state in LDS; profiles/r04_state_pool.txt) — unsorted passes only
 };
 
 Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
@@ -367,6 +377,7 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.sort_mode = o->reserved[5];
     tn.two_phase = false;
     tn.sorted = false;
+    tn.pool = false;
     // LDS stack levels per lane (+1 scratch level), 512 B per level and wave.  Measured on the Sponza
     // stand-in: camera rays rarely go deep and gain from the 8th wave per SIMD that 8 levels leave
     // room for (52.6 -> 50.6 ms); the bounce kernel, once its record fetch is quad-cooperative, prefers
@@ -419,7 +430,12 @@ LaunchCfg paths_cfg(const vmx_scene *sc, uint32_t entries, uint64_t items, int b
 // ---- split wavefront (pipeline 0): k_trace_q + k_shade + id queues ---------------------------
 int ensure_paths(vmx_scene *sc, size_t nslots, PathArrays &pa, IdQueue q[3]) {
     Workspace &ws = sc->ws;
-    const uint32_t sub_cap = (uint32_t)(nslots / kSubQueues + 1024);
+    // k_shade appends the survivors of work item i to sub-list i % 16, at most 256 per item.  Its items cover the pass's
+    // path slots — or, when the traversal kernels hand their rays on as records (k_trace_w<.., SORT>), the padded record
+    // list, which is up to 256 entries per wave of the launch longer (at most 8 blocks of 4 waves per CU): each sub-list
+    // holds its share of that, so no append can reach past it by construction
+    const size_t list_pad = (size_t)sc->num_cus * 8 * (kPathsBlock / 64) * 256;
+    const uint32_t sub_cap = (uint32_t)((nslots + list_pad) / kSubQueues + 1024);
     if (ws.rayA.ensure(nslots * 16) || ws.state.ensure(nslots * 64) || ws.hit.ensure(nslots * 8) ||
         ws.rad.ensure(nslots * 16) ||
         ws.ids[0].ensure((size_t)sub_cap * kSubQueues) || ws.ids[1].ensure((size_t)sub_cap * kSubQueues) ||
@@ -532,11 +548,38 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[3], int 
             launches += 2;
             break;
         }
+#ifdef VMX_AB_KERNELS
+        if (tn.pool) {
+            // the probe: P ray slots per block of 256 threads (VMX_AB_POOL_SLOTS, default 512), L stack levels in LDS
+            // (VMX_AB_POOL_LEVELS, default 8), as many blocks per CU as the LDS admits
+            uint32_t P = 512, Lv = 8, lds = 0;
+            if (const char *e = std::getenv("VMX_AB_POOL_SLOTS")) P = (uint32_t)std::atoi(e);
+            if (const char *e = std::getenv("VMX_AB_POOL_LEVELS")) Lv = (uint32_t)std::atoi(e);
+            if (P < 64 || P > 16384 || Lv < 1 || Lv > 64) return fail(VMX_ERR_INVALID, "k_trace_pool: bad VMX_AB_POOL_SLOTS / _LEVELS");
+            int pbl = 0;
+            HIP_TRY((hipError_t)query_trace_pool(kPathsBlock, P, Lv, &lds, &pbl));
+            if (pbl < 1) return fail(VMX_ERR_INVALID, "k_trace_pool does not fit on a CU with these slots / levels");
+            if (const char *e = std::getenv("VMX_AB_POOL_BLOCKS")) pbl = std::max(1, std::min(pbl, std::atoi(e)));
+            LaunchCfg pc;
+            pc.block = kPathsBlock, pc.lds_bytes = lds;
+            pc.grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)sc->num_cus * pbl, (total + P - 1) / P));
+            if (const char *e = std::getenv("VMX_AB_POOL_GRID")) pc.grid = (uint32_t)std::max(1, std::min((int)pc.grid, std::atoi(e)));
+            wk.pool_slots = P, wk.lds_entries = Lv;
+            wk.overflow_entries = sc->dev.stack_entries + 1 > Lv ? sc->dev.stack_entries + 1 - Lv : 1u;
+            if (ws.overflow_stack.ensure((size_t)pc.grid * P * wk.overflow_entries * 8))
+                return fail(VMX_ERR_NOMEM, "hipMalloc failed for the overflow stack");
+            wk.overflow_stack = ws.overflow_stack.p;
+            wk.reserve = 256;
+            LAUNCH_TRY(launch_trace_pool(sc->dev, wk, pa, pc, s));
+        } else
+#endif
+        {
         if (tn.sorted) {  // the traversal kernel settles the rays whose step ends by its draws and hands the others on as records
-            wk.out_rec = ws.out_rec.p, wk.out_count = ws.out_count.p, wk.out_ctr = ctr;
+            wk.out_rec = ws.out_rec.p, wk.out_count = ws.out_count.p, wk.out_ctr = ctr, wk.out_capacity = (uint32_t)ws.out_capacity;
             HIP_TRY(hipMemsetAsync(ws.out_count.p, 0, 4, s));
         }
         LAUNCH_TRY(launch_trace_q(sc->dev, fr, wk, nopx, pa, ctr, count, true, cfg, s));
+        }
         HIP_TRY(hipEventRecord(tl.b, s));
         timed.push_back(tl);
         HIP_TRY(hipMemsetAsync(q[cur ^ 1].counts, 0, kSubQueues * 32 * 4, s));
@@ -641,7 +684,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     //   4 split wavefront for every pass (form 0 hands passes of fewer than 4 M paths to form 1's
     //     kernel, which needs no per-generation host round trip)
     const uint32_t pipeline = opts->reserved[0] & 0xFFu;  // (bit 8: one-phase shading, see two_phase below)
-    if (pipeline > 4 || (opts->reserved[0] & ~0x3FFu)) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    if (pipeline > 4 || (opts->reserved[0] & ~0x7FFu)) return fail(VMX_ERR_INVALID, "unknown pipeline form");
 #ifdef VMX_AB_KERNELS
     if (sc->dev.tex && pipeline >= 2 && pipeline <= 3)
         return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
@@ -666,7 +709,15 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     // camera rays: the traversal kernel settles the rays whose step ends by its draws (and that no light sphere can
     // colour) when they finish, and hands the others on as records; reserved[0] bit 9 keeps k_shade_ends for them
     tn.sorted = tn.two_phase && !(opts->reserved[0] & 0x200u);
+#ifdef VMX_AB_KERNELS
+    tn.pool = (opts->reserved[0] & 0x400u) != 0 && !tn.sorted && !count;
+#else
+    if (opts->reserved[0] & 0x400u)
+        return fail(VMX_ERR_INVALID, "k_trace_pool (vmx_opts.reserved[0] bit 10) is a probe of the A/B library (make ab): "
+                                     "profiles/r04_state_pool.txt");
+#endif
     fr.bounce_bits = tn.sorted ? 1u : 0u;
+    fr.camera_bits = tn.two_phase ? 1u : 0u;  // read by k_trace_w<0, .., SORT> / k_shade_ends<0> only
     if (!opts->reserved[2]) {
         // measured (tools/elide_probe.py, tools/shard_probe.py): the whole frame on one GPU does not care between 2 M and
         // 16 M (86.0 / 85.8 / 85.6 / 85.8 ms at 16 / 8 / 4 / 2 M); a rank of a sharded frame does — its first bounce
@@ -698,7 +749,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     uint64_t mem_budget = 0;
     const size_t n_pad_cap = ((size_t)npix + 63u) & ~(size_t)63u;
     if (!opts->samples_per_batch && !legacy) {
-        const size_t per_path = 16 + 64 + 8 + 16 + 8 + (sc->dev.tex ? 16 : 0) + (tn.sort_mode ? 12 : 0) + (fr.elide_dead ? 5 : 0) + 32;
+        const size_t per_path = 16 + 64 + 8 + 16 + 12 /* three id lists */ + (sc->dev.tex ? 16 : 0) + (tn.sort_mode ? 12 : 0) + (fr.elide_dead ? 5 : 0) + 32;
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const size_t held = ws.rayA.n + ws.state.n + ws.hit.n + ws.rad.n + ws.thr.n + (ws.ids[0].n + ws.ids[1].n + ws.ids[2].n) * 4 +
@@ -748,9 +799,16 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the path arrays although " + std::to_string(mem_budget >> 20) +
                                            " MB were reported free: set VMX_MEM_BUDGET_MB or vmx_opts.reserved[1] (paths per pass)");
         if (rc) return rc;
-        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_primary + 1) * 512, count, false, &tb));
-        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, true, &tbb));
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_primary + 1) * 512, count, false,
+                                                        tn.sorted, fr.elide_dead != 0, &tb));
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, true,
+                                                        tn.sorted, false, &tbb));
         if (tb < 1 || tbb < 1) return fail(VMX_ERR_HIP, "trace kernel does not fit on a CU");
+#ifdef VMX_AB_KERNELS
+        // A/B library only: cap the bounce kernel's blocks per CU (how much of its time is latency hiding:
+        // profiles/r04_state_pool.txt)
+        if (const char *e = std::getenv("VMX_AB_BOUNCE_BLOCKS")) tbb = std::max(1, std::min(tbb, std::atoi(e)));
+#endif
     }
 #ifdef VMX_AB_KERNELS
     else if (legacy) {
@@ -775,7 +833,9 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
     if (split_any && tn.sorted) {
         // every path of a pass may need a record; each wave of the launch leaves at most the tail of one chunk of 256 unused
         const size_t waves = (size_t)sc->num_cus * (size_t)std::max(tb, tbb) * (kPathsBlock / 64);
-        if (ws.out_rec.ensure(((size_t)n_pad_max * smax + waves * 256 + 1024) * 32) || ws.out_count.ensure(32))
+        ws.out_capacity = (size_t)n_pad_max * smax + waves * 256 + 1024;
+        if (ws.out_capacity > 0xFFFFFFFFull) return fail(VMX_ERR_INVALID, "pass too large for the sorted ray records");
+        if (ws.out_rec.ensure(ws.out_capacity * 32) || ws.out_count.ensure(32))
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the sorted camera-ray records");
     }
     size_t live_tmp_bytes = 0;
@@ -914,7 +974,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
                 LAUNCH_TRY(launch_raygen(sc->dev, fr, wk, px, pa, s));
             }
             if (tn.sorted) {
-                wk.out_rec = ws.out_rec.p, wk.out_count = ws.out_count.p, wk.out_ctr = ws.counters.p;
+                wk.out_rec = ws.out_rec.p, wk.out_count = ws.out_count.p, wk.out_ctr = ws.counters.p, wk.out_capacity = (uint32_t)ws.out_capacity;
                 HIP_TRY(hipMemsetAsync(ws.out_count.p, 0, 4, s));
                 if (!elide) HIP_TRY(hipMemsetAsync(pa.rad_mask, 0, (size_t)(((uint64_t)n_pad * S + 63) / 64) * 8, s));
             }
@@ -1332,12 +1392,15 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     if ((opts->sampling & VMX_SAMPLING_MODE_MASK) > VMX_SAMPLING_CORRECTED ||
         (opts->sampling & ~(VMX_SAMPLING_MODE_MASK | VMX_SAMPLING_LIBM_DOUBLE | VMX_SAMPLING_ELIDE_DEAD)))
         return fail(VMX_ERR_INVALID, "unknown sampling mode");
-    if (opts->reserved[0] > 4) return fail(VMX_ERR_INVALID, "unknown pipeline form");
+    // (bits 8-10 of reserved[0] select shading / traversal forms of vmx_render's split passes and mean nothing here:
+    // accepted and ignored, as render_impl accepts them)
+    const uint32_t pipeline = opts->reserved[0] & 0xFFu;
+    if (pipeline > 4 || (opts->reserved[0] & ~0x7FFu)) return fail(VMX_ERR_INVALID, "unknown pipeline form");
 #ifdef VMX_AB_KERNELS
-    if (sc->dev.tex && opts->reserved[0] >= 2 && opts->reserved[0] <= 3)
+    if (sc->dev.tex && pipeline >= 2 && pipeline <= 3)
         return fail(VMX_ERR_INVALID, "the first-generation kernels (pipeline forms 2, 3) do not sample textures");
 #else
-    if (opts->reserved[0] >= 2 && opts->reserved[0] <= 3)
+    if (pipeline >= 2 && pipeline <= 3)
         return fail(VMX_ERR_INVALID, "pipeline forms 2 and 3 (first-generation kernels) are only in the A/B library (make ab)");
 #endif
     if (n == 0) return VMX_OK;
@@ -1348,9 +1411,12 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     Workspace &ws = sc->ws;
     hipStream_t s = sc->stream;
     const bool count = opts->collect_counters != 0;
-    const bool legacy = opts->reserved[0] == 2 || opts->reserved[0] == 3;  // first-generation kernels
+    const bool legacy = pipeline == 2 || pipeline == 3;  // first-generation kernels
     (void)legacy;
-    const Tuning tn = make_tuning(sc, opts);
+    Tuning tn = make_tuning(sc, opts);
+#ifdef VMX_AB_KERNELS
+    tn.pool = (opts->reserved[0] & 0x400u) != 0 && !count;  // the phase-pure probe (vmx_trace_pool.inc)
+#endif
     FrameDev fr;
     std::memset(&fr, 0, sizeof(fr));
     fr.r2scale = (opts->sampling & VMX_SAMPLING_MODE_MASK) == VMX_SAMPLING_CORRECTED ? 1.0f : 10.0f;
@@ -1375,7 +1441,8 @@ int vmx_radiance(const vmx_scene *csc, const float *origin, const float *dir, ui
     {
         rc = ensure_paths(sc, n, pa, qi);
         if (rc) return rc;
-        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, true, &tb));
+        HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, true,
+                                                        false, false, &tb));
         HIP_TRY((hipError_t)query_paths_blocks_per_cu(kPathsBlock, lds_paths, count, &rb));
     }
     DevBuf<float> d_o, d_d;
@@ -1658,6 +1725,13 @@ struct vmx_multi {
     std::vector<int> route;
     DevBuf<float> gathered, frame;     // on the root = replica[0]'s device
     std::mutex mu;
+    // the exchange step of the last render, timed apart from the rendering ("gather time separately"):
+    // per replica the device time of its render and of its stripes' copy into the root's gather buffer (hipEvent pairs
+    // on the replica's stream), the de-interleave kernel on the root, and the host's wall clock around all of it
+    std::vector<double> render_ms, copy_ms;
+    std::vector<hipEvent_t> copy_ev;   // two per replica, created on the replica's device by its worker
+    hipEvent_t asm_ev[2] = {nullptr, nullptr};
+    double assemble_ms = 0.0, wall_ms = 0.0;
 };
 
 namespace {
@@ -1683,6 +1757,9 @@ int multi_render(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, floa
     std::vector<int> rc(world, VMX_OK);
     std::vector<std::string> msg(world);
     std::vector<vmx_stats> st(world);
+    const auto wall0 = std::chrono::steady_clock::now();
+    m->render_ms.assign(world, 0.0), m->copy_ms.assign(world, 0.0);
+    m->copy_ev.resize((size_t)world * 2, nullptr);
     for (uint32_t r = 0; r < world; ++r) {
         m->worker[r]->submit([&, r]() {
             vmx_scene *sc = m->replica[r];
@@ -1697,9 +1774,17 @@ int multi_render(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, floa
                 if (sc->ws.out.ensure(nfloats)) return fail(VMX_ERR_NOMEM, "hipMalloc failed for the frame buffer");
                 e = render_one(sc, &o, sc->ws.out.p, &st[r]);
                 if (e) return e;
+                hipEvent_t *ev = &m->copy_ev[(size_t)r * 2];
+                for (int k = 0; k < 2; ++k)
+                    if (!ev[k]) HIP_TRY(hipEventCreate(&ev[k]));
+                HIP_TRY(hipEventRecord(ev[0], sc->stream));
                 HIP_TRY(hipMemcpyPeerAsync(m->gathered.p + (size_t)stride * r, root->device, sc->ws.out.p, sc->device,
                                            nfloats * 4, sc->stream));
+                HIP_TRY(hipEventRecord(ev[1], sc->stream));
                 HIP_TRY(hipStreamSynchronize(sc->stream));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                m->copy_ms[r] = ms, m->render_ms[r] = st[r].ms_device;
                 return VMX_OK;
             };
             std::memset(&st[r], 0, sizeof(vmx_stats));
@@ -1713,9 +1798,19 @@ int multi_render(vmx_multi *m, const vmx_camera *cam, const vmx_opts *opts, floa
 
     HIP_TRY(hipSetDevice(root->device));
     float *d_frame = d_out_root ? (float *)d_out_root : m->frame.p;
+    for (int k = 0; k < 2; ++k)
+        if (!m->asm_ev[k]) HIP_TRY(hipEventCreate(&m->asm_ev[k]));
+    HIP_TRY(hipEventRecord(m->asm_ev[0], root->stream));
     LAUNCH_TRY(launch_assemble(m->gathered.p, stride, W, H, stripe, world, d_frame, root->stream));
+    HIP_TRY(hipEventRecord(m->asm_ev[1], root->stream));
     if (out_host) HIP_TRY(hipMemcpyAsync(out_host, d_frame, (size_t)W * H * 5 * 4, hipMemcpyDeviceToHost, root->stream));
     HIP_TRY(hipStreamSynchronize(root->stream));
+    {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, m->asm_ev[0], m->asm_ev[1]));
+        m->assemble_ms = ms;
+        m->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         for (uint32_t r = 0; r < world; ++r) {
@@ -1821,7 +1916,14 @@ int vmx_multi_create(const float *pos, const float *nrm, const float *uv, uint32
 int vmx_multi_destroy(vmx_multi *m) {
     if (!m) return VMX_OK;
     for (auto &w : m->worker) w->stop();
+    for (size_t i = 0; i < m->copy_ev.size(); ++i)
+        if (m->copy_ev[i]) {
+            (void)hipSetDevice(m->replica[i / 2]->device);
+            (void)hipEventDestroy(m->copy_ev[i]);
+        }
     if (!m->replica.empty()) (void)hipSetDevice(m->replica[0]->device);
+    for (int k = 0; k < 2; ++k)
+        if (m->asm_ev[k]) (void)hipEventDestroy(m->asm_ev[k]);
     m->gathered.release(), m->frame.release();
     for (vmx_scene *sc : m->replica) vmx_scene_destroy(sc);
     delete m;
@@ -1836,6 +1938,24 @@ int vmx_multi_routes(const vmx_multi *m, int *devices, int *routes) {
         if (devices) devices[i] = m->replica[i]->device;
         if (routes) routes[i] = m->route[i];
     }
+    return VMX_OK;
+}
+
+int vmx_multi_timings(const vmx_multi *cm, vmx_multi_times *out, double *render_ms, double *copy_ms) {
+    vmx_multi *m = const_cast<vmx_multi *>(cm);
+    if (!m || !out) return fail(VMX_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(m->mu);
+    std::memset(out, 0, sizeof(*out));
+    out->world = (uint32_t)m->replica.size();
+    for (size_t r = 0; r < m->render_ms.size(); ++r) {
+        out->slowest_render_ms = std::max(out->slowest_render_ms, m->render_ms[r]);
+        out->gather_ms = std::max(out->gather_ms, m->copy_ms[r]);
+        out->gather_sum_ms += m->copy_ms[r];
+        if (render_ms) render_ms[r] = m->render_ms[r];
+        if (copy_ms) copy_ms[r] = m->copy_ms[r];
+    }
+    out->assemble_ms = m->assemble_ms;
+    out->wall_ms = m->wall_ms;
     return VMX_OK;
 }
 

@@ -105,9 +105,12 @@ struct FrameDev {
     uint32_t libm_double;         // VMX_SAMPLING_LIBM_DOUBLE: cos/sin(float r1) of pathtracer.cpp:162 as C's double functions
     uint32_t elide_dead;          // VMX_SAMPLING_ELIDE_DEAD: camera paths with provably zero radiance are not traced
     uint32_t bounce_bits;         // k_shade stores step_bits of the next step with every bounce ray (k_trace_w<1, .., SORT>)
+    uint32_t camera_bits;         // k_raygen writes step_bits of the first step with every camera ray (read by k_trace_w<0, .., SORT>
+                                  // and k_shade_ends<0>; a frame whose steps are all shaded in full does not draw them)
     uint32_t local_rows;          // rows owned by this rank
     uint32_t stripe_rows, rank, world;
     uint64_t seed;
+    double inv_width, inv_height;  // RN(1 / width), RN(1 / height) by IEEE division on the host (div_by_count)
 };
 
 // Path state across a bounce boundary: 6 planes of 16 bytes, plane p of slot s

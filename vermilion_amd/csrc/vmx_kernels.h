@@ -79,6 +79,9 @@ struct WorkDev {
     void *out_rec;
     unsigned int *out_count;
     DevCounters *out_ctr;
+    uint32_t pool_slots;    // A/B library: ray slots per block of k_trace_pool (vmx_trace_pool.inc)
+    uint32_t out_capacity;  // entries the list holds (paths of the pass + 256 per wave of the launch): an append never
+                            // writes at or past it, and a count beyond it is reported (DevCounters::overflow)
     // two-phase shading: the ordered list of positions k_shade_ends left for k_shade (NULL: one phase)
     const unsigned int *flat_ids;
     const unsigned int *flat_count;
@@ -121,6 +124,9 @@ int launch_bounce(const SceneDev &sc, float r2scale, uint32_t libm_double, Queue
                   void *rad, DevCounters *counters, bool count, bool loop_to_end, bool first_step,
                   LaunchCfg cfg, void *stream);
 int query_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, int *primary_blocks, int *bounce_blocks);
+// phase-pure bounce traversal with the ray state in LDS (vmx_trace_pool.inc; profiles/r04_state_pool.txt)
+int launch_trace_pool(const SceneDev &sc, const WorkDev &wk, PathArrays pa, LaunchCfg cfg, void *stream);
+int query_trace_pool(uint32_t block, uint32_t pool_slots, uint32_t lds_levels, uint32_t *lds_bytes, int *blocks);
 #endif
 // per-pixel accumulation in sample order, early-stop rule, pixel write, next active list
 // persistent fused kernel with per-lane refill (ray generation source): every lane keeps its path to the end
@@ -137,7 +143,7 @@ int launch_live_compact(const unsigned long long *live_mask, const unsigned int 
                         unsigned int *offs, unsigned int *ids, unsigned int *count, void *tmp, size_t tmp_bytes, void *stream);
 int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                    DevCounters *counters, bool count, bool from_queue, LaunchCfg cfg, void *stream);
-int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, bool from_queue, int *blocks);
+int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, bool from_queue, bool sorted, bool live, int *blocks);
 // ... and the wide shading kernel: RayCast tail + Radiance step + id compaction
 int launch_shade(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, PixelStateDev px, PathArrays pa,
                  IdQueue qout, uint32_t max_chunks, DevCounters *counters, bool from_queue, void *stream);

@@ -81,16 +81,31 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 
+// Stream of sample k of pixel p (the reference seeds a thread-local mt19937_64 from std::random_device,
+// pathtracer.cpp:231, and is not reproducible: the stream definition is this build's own, shared with the oracle).
+// Round 4: the pixel half of the key is two mix64 per PIXEL — a wave of k_raygen / k_shade<0> is 64 samples of one pixel,
+// so it runs once per wave on the scalar unit — and the sample half costs three 64-bit multiplies (round 3: ten per
+// sample, twice per camera path):
+//   a = mix64(seed ^ (p << 32))   b = mix64(a + golden)                       per pixel
+//   s0 = mix64(a + k)   t = (s0 ^ b) * M3   s1 = t ^ (t >> 32)   s2 = rotl(s0, 24) ^ b   s3 = rotl(s1, 37) ^ a
+struct PixelKey {
+    uint64_t a, b;
+};
+__device__ __forceinline__ PixelKey rng_pixel_key(uint64_t seed, uint32_t pixel) {
+    PixelKey pk;
+    pk.a = mix64(seed ^ ((uint64_t)pixel << 32));
+    pk.b = mix64(pk.a + 0x9E3779B97F4A7C15ull);
+    return pk;
+}
+__device__ __forceinline__ void rng_init_keyed(Rng &r, PixelKey pk, uint32_t k) {
+    r.s0 = mix64(pk.a + (uint64_t)k);
+    const uint64_t t = (r.s0 ^ pk.b) * 0xD6E8FEB86659FD93ull;
+    r.s1 = t ^ (t >> 32);
+    r.s2 = rotl64(r.s0, 24) ^ pk.b;
+    r.s3 = rotl64(r.s1, 37) ^ pk.a;
+}
 __device__ __forceinline__ void rng_init(Rng &r, uint64_t seed, uint32_t pixel, uint32_t k) {
-    uint64_t x = mix64(seed ^ (((uint64_t)pixel << 32) | (uint64_t)k));
-    x += 0x9E3779B97F4A7C15ull;
-    r.s0 = mix64(x);
-    x += 0x9E3779B97F4A7C15ull;
-    r.s1 = mix64(x);
-    x += 0x9E3779B97F4A7C15ull;
-    r.s2 = mix64(x);
-    x += 0x9E3779B97F4A7C15ull;
-    r.s3 = mix64(x);
+    rng_init_keyed(r, rng_pixel_key(seed, pixel), k);
 }
 
 __device__ __forceinline__ uint64_t rng_next(Rng &r) {
@@ -850,6 +865,21 @@ __device__ __forceinline__ void tally_flush(DevCounters *ctr, const Tally &tl, c
 // ---------------------------------------------------------------------------
 // ray generation (pathtracer.cpp:251-280); p = global pixel index, k = linear sample index
 // ---------------------------------------------------------------------------
+// a / n in double, correctly rounded, for an integer 1 <= n < 2^32 whose reciprocal y = RN(1 / n) the host computed by an
+// IEEE division (FrameDev::inv_width / inv_height): three operations instead of the ~35 of a double division, two of
+// which sat in every camera ray's generation (pathtracer.cpp:251-252 divide by the image size in double).  Markstein's
+// correction step: q0 = RN(a y) is within 2 ulp of a / n; e = a - n q0 is exact in an FMA (a multiple of ulp(q0), at
+// most 2^33 of them); q0 + e y = a / n + (e / n) delta with |delta| <= 2^-53, i.e. within 2^-104 relative of a / n —
+// while a / n, n an integer below 2^32, is either a double or at least 2^-86 relative away from every midpoint
+// between two doubles (a - m n, m such a midpoint, is a non-zero multiple of ulp(m) / 2: m n has more than 53
+// significant bits and cannot equal a).  So RN(q0 + e y) = RN(a / n), for every finite a.  Checked exhaustively on
+// the CPU for every float a camera ray can produce at the bench's and the tests' image sizes
+// (tests/test_kernel_shortcuts.py::test_division_by_the_image_size...).
+__device__ __forceinline__ double div_by_count(double a, uint32_t n, double y) {
+    const double q0 = a * y;
+    const double e = __fma_rn(-q0, (double)n, a);
+    return __fma_rn(e, y, q0);
+}
 __device__ __forceinline__ void primary_ray(const FrameDev &fr, uint32_t p, uint32_t k, Rng &rng, float &dx,
                                             float &dy, float &dz) {
     rng_init(rng, fr.seed, p, k);
@@ -859,8 +889,8 @@ __device__ __forceinline__ void primary_ray(const FrameDev &fr, uint32_t p, uint
     const float sx = (float)(s >> 1), sy = (float)(s & 1u);
     const float fx = (float)(p % fr.width) + (sx * 0.5f - 0.5f) + jx;
     const float fy = (float)(p / fr.width) + (sy * 0.5f - 0.5f) + jy;
-    const float hx = (float)((((double)fx - 0.25) / (double)fr.width) - 0.5);
-    const float hy = (float)((((double)fy - 0.25) / (double)fr.height) - 0.5);
+    const float hx = (float)(div_by_count((double)fx - 0.25, fr.width, fr.inv_width) - 0.5);
+    const float hy = (float)(div_by_count((double)fy - 0.25, fr.height, fr.inv_height) - 0.5);
     const float gx = hx * fr.sensor_x, gy = -(hy * fr.sensor_y), gz = -fr.film_dist;
     // cameraTransform * gridPane, GLM order (m0*x + m1*y) + (m2*z + m3*w), m3.xyz = 0, w = 1
     float rx = (fr.m[0] * gx + fr.m[3] * gy) + (fr.m[6] * gz + 0.0f);
@@ -924,7 +954,9 @@ __device__ __forceinline__ void id_append(const IdQueue &q, uint32_t sub, bool a
     if (lane == 0) base = atomicAdd(&q.counts[sub * 32], (uint32_t)__popcll(m));
     base = __builtin_amdgcn_readfirstlane(base);
     const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (alive) q.ids[(size_t)sub * q.sub_capacity + base + rank] = pid;
+    // (the sub-lists are sized so that this cannot fail — ensure_paths — but an append never writes past its list: the
+    // tail counter then stays above sub_capacity, which the host reads as an error, run_ids / finish_stats)
+    if (alive && base + rank < q.sub_capacity) q.ids[(size_t)sub * q.sub_capacity + base + rank] = pid;
 }
 
 // Path id of sample plane j of active-pixel slot s.  pixel_major: the samples of one pixel are
@@ -1463,7 +1495,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
                     Rng rng;
                     primary_ray(fr, global_pixel(fr, lp), k, rng, dx, dy, dz);
                     if (LIVE) live = !step_is_dead<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
-                    else depth = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+                    else depth = fr.camera_bits ? step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f) : 0u;
                 }
                 if (!LIVE) ((float4 *)pa.rayA)[pid0 + lane] = make_float4(dx, dy, dz, __uint_as_float(depth));
             } else if (!LIVE) {  // padding slots of the pass: marked like sample slots past a pixel's last sample
@@ -1489,7 +1521,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
             if (LIVE) live = !step_is_dead<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
-            else depth = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+            else depth = fr.camera_bits ? step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f) : 0u;
         }
         // camera rays share the origin (FrameDev): one 16-byte record in rayA — direction, and a word that is ~0 for a
         // slot without a sample (past the pixel's last one, or padding), else the step's step_bits
@@ -1516,7 +1548,7 @@ k_raygen_live(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays
         if (primary_item(fr, wk, px, j, s_idx, pid2, pixel, k)) {  // (always: the path was found live from the same item)
             Rng rng;
             primary_ray(fr, pixel, k, rng, dx, dy, dz);
-            depth = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+            depth = fr.camera_bits ? step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f) : 0u;
         }
         ((float4 *)pa.rayA)[i] = make_float4(dx, dy, dz, __uint_as_float(depth));
     }
@@ -2121,9 +2153,13 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
             } else {
                 out_lo += n;
             }
-            if (todo) {
+            // (the list is sized for every path of the pass + one chunk per wave, so `at` cannot reach its end; an entry
+            // that would is dropped and reported instead of written — never a store past the allocation)
+            if (todo && at < wk.out_capacity) {
                 if (SRC == 0) rec[(size_t)at * kRec] = make_float4(dx, dy, dz, __uint_as_float(rflags & 7u));  // (bounce paths: ray and stream are in state[pid])
                 rec[(size_t)at * kRec + (kRec - 1)] = make_float4(best, __int_as_float(slot), __uint_as_float(pid), 0.f);
+            } else if (todo) {
+                atomicAdd(&wk.out_ctr->overflow, 1ull);
             }
         }
         rflags &= 0x7FFFFFFFu;
@@ -2473,7 +2509,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         sort_finished();
         float4 *__restrict__ rec = (float4 *)wk.out_rec;
         constexpr uint32_t kRec = SRC == 0 ? 2 : 1;
-        for (uint32_t i = out_lo + lane; i < out_hi; i += 64u) rec[(size_t)i * kRec + (kRec - 1)] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
+        for (uint32_t i = out_lo + lane; i < min(out_hi, wk.out_capacity); i += 64u) rec[(size_t)i * kRec + (kRec - 1)] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFFFFFu), 0.f);
         if (lane == 0) {
             if (n_rays) atomicAdd(&wk.out_ctr->stage[SRC].rays, (unsigned long long)n_rays);
             if (n_hits) atomicAdd(&wk.out_ctr->stage[SRC].tri_hits, (unsigned long long)n_hits);
@@ -2528,7 +2564,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
     uint32_t items = (SRC == 0 ? (wk.samples * wk.n_pad + blockDim.x - 1) / blockDim.x : max_chunks * kSubQueues);
     uint32_t flat_n = 0;
     if (FROMQ == 1) flat_n = *wk.flat_count, items = (flat_n + blockDim.x - 1) / blockDim.x;
-    if (FROMQ == 2) flat_n = *wk.out_count, items = (flat_n + blockDim.x - 1) / blockDim.x;
+    if (FROMQ == 2) flat_n = min(*wk.out_count, wk.out_capacity), items = (flat_n + blockDim.x - 1) / blockDim.x;
     // VMX_SAMPLING_ELIDE_DEAD: the pass's live camera paths only; ray and hit record sit at the list position `src`
     constexpr bool listed = SRC == 0 && ELIDE;
     uint32_t live_n = 0;
@@ -2565,7 +2601,14 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
                 // the ray comes from k_raygen; the stream is re-keyed and its two jitter draws skipped
                 const float4 a = FROMQ == 2 ? rec0 : ((const float4 *)pa.rayA)[src];
                 P.ox = fr.px, P.oy = fr.py, P.oz = fr.pz, P.dx = a.x, P.dy = a.y, P.dz = a.z, P.depth = 0;
-                rng_init(P.rng, fr.seed, pixel, k);
+                if (FROMQ == 0 && !listed && wk.pixel_major && (wk.samples & 63u) == 0) {
+                    // the wave's 64 paths are 64 samples of ONE pixel (path ids of an item are consecutive): the pixel
+                    // half of the key once per wave, on the scalar unit
+                    const uint32_t pu = (uint32_t)__builtin_amdgcn_readfirstlane((int)pixel);
+                    rng_init_keyed(P.rng, rng_pixel_key(fr.seed, pu), k);
+                } else {
+                    rng_init(P.rng, fr.seed, pixel, k);
+                }
                 (void)rng_next(P.rng);
                 (void)rng_next(P.rng);
                 P.ar = P.ag = P.ab = 0.f;
@@ -3351,16 +3394,22 @@ int launch_trace_q(const SceneDev &sc, const FrameDev &fr, const WorkDev &wk, Pi
     return launch_status();
 }
 
-int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, bool from_queue, int *blocks) {
+// occupancy of the exact instantiation launch_trace_q selects (sorted: k_trace_w<.., SORT>; live: the ELIDE_DEAD list
+// form of the camera kernel): the persistent grid and the record-list padding are sized from it
+int query_trace_q_blocks_per_cu(uint32_t block, uint32_t lds_bytes, bool count, bool from_queue, bool sorted, bool live, int *blocks) {
     int a = 0;
     hipError_t e;
+#define VMX_OCC(K) hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, K, (int)block, lds_bytes)
     if (count) {
-        e = from_queue ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 1>, (int)block, lds_bytes)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_q<true, 0>, (int)block, lds_bytes);
+        e = from_queue ? VMX_OCC((k_trace_q<true, 1>)) : VMX_OCC((k_trace_q<true, 0>));
+    } else if (from_queue) {
+        e = sorted ? VMX_OCC((k_trace_w<1, false, true>)) : VMX_OCC((k_trace_w<1>));
+    } else if (sorted) {
+        e = live ? VMX_OCC((k_trace_w<0, true, true>)) : VMX_OCC((k_trace_w<0, false, true>));
     } else {
-        e = from_queue ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_w<1>, (int)block, lds_bytes)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_w<0>, (int)block, lds_bytes);
+        e = live ? VMX_OCC((k_trace_w<0, true>)) : VMX_OCC((k_trace_w<0>));
     }
+#undef VMX_OCC
     if (blocks) *blocks = a;
     return (int)e;
 }
@@ -3498,6 +3547,7 @@ int launch_quantize(const float *frame, uint64_t npix, void *rgba8, float *depth
 #ifdef VMX_AB_KERNELS
 // first-generation kernels (pipeline forms 2, 3): only in the A/B library of `make ab`, never in the product
 #include "vmx_kernels_ab.inc"
+#include "vmx_trace_pool.inc"
 #endif
 
 }  // namespace vmx

@@ -38,19 +38,47 @@ def assemble_host(parts, width, height, stripe_rows, world):
     return frame
 
 
-def gather_frame(local, width, height, stripe_rows, rank, world, dst=0, group=None):
+class ExchangeTimes:
+    """The exchange step of gather_frame timed apart from the rendering ("gather time separately"): event
+    pairs on the current HIP stream around the gather and around the de-interleave kernel (wall-clock pairs for CPU
+    tensors).  Read with ms() once the stream has been synchronised."""
+
+    def __init__(self):
+        self.pairs = {"gather": [], "assemble": []}
+
+    def mark(self, cuda_device):
+        import time
+        if cuda_device is None:
+            return time.perf_counter()
+        import torch
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(cuda_device))
+        return e
+
+    def ms(self, key):
+        """summed over the calls since construction"""
+        tot = 0.0
+        for a, b in self.pairs[key]:
+            tot += (b - a) * 1e3 if isinstance(a, float) else a.elapsed_time(b)
+        return tot
+
+
+def gather_frame(local, width, height, stripe_rows, rank, world, dst=0, group=None, times=None):
     """Gather the packed per-rank stripes to `dst` and de-interleave them there.
 
     local: torch tensor [local_rows, W, 5] (cuda -> RCCL gather + HIP assemble
     kernel; cpu -> gloo gather + index assembly).  Returns the [H, W, 5] frame
-    on dst, None elsewhere.  world == 1 returns `local` unchanged."""
+    on dst, None elsewhere.  world == 1 returns `local` unchanged.
+    times: an ExchangeTimes that collects the gather's and the assembly's durations."""
     import torch
     import torch.distributed as dist
 
     if world <= 1:
         return local
+    dev = local.device if local.is_cuda else None
     mrows = max_local_rows(height, stripe_rows, world)
     stride = mrows * width * 5
+    t0 = times.mark(dev) if times else None
     padded = local.new_zeros((stride,))
     padded[: local.numel()] = local.reshape(-1)
     if rank == dst:
@@ -59,12 +87,19 @@ def gather_frame(local, width, height, stripe_rows, rank, world, dst=0, group=No
         dist.gather(padded, gather_list=views, dst=dst, group=group)
     else:
         dist.gather(padded, gather_list=None, dst=dst, group=group)
+        if times:
+            times.pairs["gather"].append((t0, times.mark(dev)))
         return None
+    t1 = times.mark(dev) if times else None
     if big.is_cuda:
         frame = torch.empty((height, width, 5), dtype=torch.float32, device=big.device)
         stream = torch.cuda.current_stream(big.device).cuda_stream
         L.check(L.lib().vmx_assemble_device(C.c_void_p(big.data_ptr()), stride, width, height, stripe_rows, world,
                                             C.c_void_p(frame.data_ptr()), big.device.index or 0,
                                             C.c_void_p(stream)))
-        return frame
-    return assemble_host([v.view(mrows, width, 5) for v in views], width, height, stripe_rows, world)
+    else:
+        frame = assemble_host([v.view(mrows, width, 5) for v in views], width, height, stripe_rows, world)
+    if times:
+        times.pairs["gather"].append((t0, t1))
+        times.pairs["assemble"].append((t1, times.mark(dev)))
+    return frame

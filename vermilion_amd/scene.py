@@ -16,12 +16,18 @@ def _f32(a, shape_last=None):
     return a
 
 
-def make_camera(position, rotation_deg, width, height, spp, back_distance=6.0, back_size=(3.6, 2.4)):
+def make_camera(position, rotation_deg, width, height, spp, back_distance=6.0, back_size=(3.6, 2.4), rotation_rad=None):
     """cameraSettings subset (core/camera/camera.h:32-47); defaults follow
-    RenderEngine::CreateInternalDefaultCamera (core/engines/renderEngine.cpp:135-139)."""
+    RenderEngine::CreateInternalDefaultCamera (core/engines/renderEngine.cpp:135-139).
+    rotation_rad: Camera::mRotation itself (radians, x and y already negated, camera.cpp:43-47) instead of the
+    settings' degrees — what an Integrator holds (VMX_ROTATION_RADIANS)."""
     c = L.CameraDesc()
     c.position[:] = [float(v) for v in position]
-    c.rotation_deg[:] = [float(v) for v in rotation_deg]
+    if rotation_rad is not None:
+        c.rotation_units = L.VMX_ROTATION_RADIANS
+        c.rotation_rad[:] = [float(v) for v in rotation_rad]
+    else:
+        c.rotation_deg[:] = [float(v) for v in rotation_deg]
     c.back_distance = float(back_distance)
     c.back_size[:] = [float(back_size[0]), float(back_size[1])]
     c.image_res[:] = [int(width), int(height)]
@@ -251,6 +257,15 @@ class MultiScene:
         d, r = (C.c_int * self.world)(), (C.c_int * self.world)()
         L.check(L.lib().vmx_multi_routes(self._h, d, r))
         return list(zip(list(d), list(r)))
+
+    def timings(self):
+        """the exchange step of the last render, timed apart from the rendering (vmx_multi_timings)"""
+        t = L.MultiTimes()
+        r, c = (C.c_double * self.world)(), (C.c_double * self.world)()
+        L.check(L.lib().vmx_multi_timings(self._h, C.byref(t), r, c))
+        d = {k: getattr(t, k) for k, _ in t._fields_ if k != "pad"}
+        d["render_ms"], d["copy_ms"] = list(r), list(c)
+        return d
 
     def bind_texture(self, data):
         data = np.ascontiguousarray(data, dtype=np.float32)
