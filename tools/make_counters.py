@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # step shaded in full (vmx_opts.reserved[0] bit 8, bench.py HEADLINE_FORM)
 CLASSES = [
     ("raygen", "k_raygen<0>"), ("trace_camera", "k_trace_w<0, false, false>"), ("shade_camera", "k_shade<0, false, false, 0>"),
-    ("trace_bounce", "k_trace_w<1, false, false>"), ("shade_bounce", "k_shade<1, false, false, 0>"),
+    # (one-phase bounce generations go through dense ray records, all kept: the SORT instantiation with WorkDev::keep_all)
+    ("trace_bounce", "k_trace_w<1, false, true>"), ("shade_bounce", "k_shade<1, false, false, 2>"),
     ("tail", "k_paths<false, 2"), ("fused", "k_paths<false, 0"), ("resolve", "k_resolve"),
 ]
 HEADLINE_FORM = 0x100

@@ -360,6 +360,9 @@ struct Tuning {
     uint32_t sort_mode;  // bounce reordering: obits | dbits << 4 | dir_major << 8 | chunk_log2 << 12 | shade_sorted << 20
     bool two_phase;      // split passes of vmx_render: k_shade_ends + k_shade on what it queues (render_impl)
     bool sorted;         // ... and the camera rays sorted by the trace kernel itself (k_trace_w<0, .., SORT>): no k_shade_ends
+    bool bounce_records; // one-phase shading of a render pass's bounce generations: the traversal kernel hands every ray on as a
+                         // dense (t, leaf slot, path id) record (k_trace_w<1, .., SORT> with WorkDev::keep_all) instead of a
+                         // scattered 8-byte hit[pid] store that k_shade<1> then gathers — same shading, every ray a full RayCast
     bool pool;           // A/B library, reserved[0] bit 10: the bounce generations of a pass through k_trace_pool (phase-pure
                          // steps, ray state in LDS; profiles/r04_state_pool.txt) — unsorted passes only
 };
@@ -377,6 +380,7 @@ Tuning make_tuning(const vmx_scene *sc, const vmx_opts *o) {
     tn.sort_mode = o->reserved[5];
     tn.two_phase = false;
     tn.sorted = false;
+    tn.bounce_records = false;
     tn.pool = false;
     // LDS stack levels per lane (+1 scratch level), 512 B per level and wave.  Measured on the Sponza
     // stand-in: camera rays rarely go deep and gain from the 8th wave per SIMD that 8 levels leave
@@ -574,8 +578,9 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[3], int 
         } else
 #endif
         {
-        if (tn.sorted) {  // the traversal kernel settles the rays whose step ends by its draws and hands the others on as records
+        if (tn.sorted || tn.bounce_records) {  // the traversal kernel settles the rays whose step ends by its draws and hands the others on as records (bounce_records: hands all of them on)
             wk.out_rec = ws.out_rec.p, wk.out_count = ws.out_count.p, wk.out_ctr = ctr, wk.out_capacity = (uint32_t)ws.out_capacity;
+            wk.keep_all = tn.sorted ? 0u : 1u;
             HIP_TRY(hipMemsetAsync(ws.out_count.p, 0, 4, s));
         }
         LAUNCH_TRY(launch_trace_q(sc->dev, fr, wk, nopx, pa, ctr, count, true, cfg, s));
@@ -588,7 +593,7 @@ int run_ids(vmx_scene *sc, const FrameDev &fr, PathArrays pa, IdQueue q[3], int 
         HIP_TRY(hipEventRecord(ts.a, s));
         wk.qids = q_shade;
         const uint32_t max_chunks = (largest + 255) / 256;
-        if (tn.sorted) {
+        if (tn.sorted || tn.bounce_records) {
             LAUNCH_TRY(launch_shade(sc->dev, fr, wk, nopx, pa, q[cur ^ 1], max_chunks, ctr, true, s));
         } else if (tn.two_phase) {
             rc = shade_two_phase(sc, fr, wk, nopx, pa, q, q[cur ^ 1], max_chunks, (size_t)max_chunks * kSubQueues * 4, false, ctr, true, s);
@@ -802,7 +807,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
         HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_primary + 1) * 512, count, false,
                                                         tn.sorted, fr.elide_dead != 0, &tb));
         HIP_TRY((hipError_t)query_trace_q_blocks_per_cu(kPathsBlock, (kPathsBlock / 64) * (tn.lds_bounce + 1) * 512, count, true,
-                                                        tn.sorted, false, &tbb));
+                                                        tn.sorted || (!tn.two_phase && !count && !tn.pool && fr.r2scale == 10.0f), false, &tbb));
         if (tb < 1 || tbb < 1) return fail(VMX_ERR_HIP, "trace kernel does not fit on a CU");
 #ifdef VMX_AB_KERNELS
         // A/B library only: cap the bounce kernel's blocks per CU (how much of its time is latency hiding:
@@ -830,13 +835,20 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             return fail(VMX_ERR_NOMEM, "hipMalloc failed for the two-phase shading lists");
         ws.full_words = words, ws.full_tmp_bytes = tmp;
     }
-    if (split_any && tn.sorted) {
+    // one-phase shading (no two_phase): the bounce generations still go through dense ray records, all of them kept
+    // (reference sampling only: there one path in seven goes on, and the gathered 8-byte hit records were a quarter of
+    // k_shade<1>'s traffic — 5.9 -> 5.2 ms on the bench frame.  Under `corrected` sampling nearly every path goes on, and
+    // records arrive in the order the rays FINISH, which scatters the state reads and writes that the id queue's order
+    // keeps nearly sequential: measured 243 -> 328 ms of shading per 64-spp frame, so that form keeps hit[pid])
+    tn.bounce_records = split_any && !tn.two_phase && !count && !tn.pool && fr.r2scale == 10.0f;
+    if (split_any && (tn.sorted || tn.bounce_records)) {
         // every path of a pass may need a record; each wave of the launch leaves at most the tail of one chunk of 256 unused
+        // (camera-ray records are 32 bytes, bounce-ray records 16)
         const size_t waves = (size_t)sc->num_cus * (size_t)std::max(tb, tbb) * (kPathsBlock / 64);
         ws.out_capacity = (size_t)n_pad_max * smax + waves * 256 + 1024;
         if (ws.out_capacity > 0xFFFFFFFFull) return fail(VMX_ERR_INVALID, "pass too large for the sorted ray records");
-        if (ws.out_rec.ensure(ws.out_capacity * 32) || ws.out_count.ensure(32))
-            return fail(VMX_ERR_NOMEM, "hipMalloc failed for the sorted camera-ray records");
+        if (ws.out_rec.ensure(ws.out_capacity * (tn.sorted ? 32 : 16)) || ws.out_count.ensure(32))
+            return fail(VMX_ERR_NOMEM, "hipMalloc failed for the ray records");
     }
     size_t live_tmp_bytes = 0;
     if (elide) {

@@ -79,6 +79,8 @@ struct WorkDev {
     void *out_rec;
     unsigned int *out_count;
     DevCounters *out_ctr;
+    uint32_t keep_all;      // k_trace_w<.., SORT>: hand EVERY finished ray on as a record, settle none (the one-phase form
+                            // of a bounce generation: k_shade reads dense (t, leaf slot, path id) records instead of hit[pid])
     uint32_t pool_slots;    // A/B library: ray slots per block of k_trace_pool (vmx_trace_pool.inc)
     uint32_t out_capacity;  // entries the list holds (paths of the pass + 256 per wave of the launch): an append never
                             // writes at or past it, and a count beyond it is reported (DevCounters::overflow)

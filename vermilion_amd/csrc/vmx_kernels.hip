@@ -880,9 +880,10 @@ __device__ __forceinline__ double div_by_count(double a, uint32_t n, double y) {
     const double e = __fma_rn(-q0, (double)n, a);
     return __fma_rn(e, y, q0);
 }
-__device__ __forceinline__ void primary_ray(const FrameDev &fr, uint32_t p, uint32_t k, Rng &rng, float &dx,
-                                            float &dy, float &dz) {
-    rng_init(rng, fr.seed, p, k);
+// (pk: the pixel half of the stream key, which a caller that walks the samples of one pixel forms once)
+__device__ __forceinline__ void primary_ray_keyed(const FrameDev &fr, uint32_t p, PixelKey pk, uint32_t k, Rng &rng, float &dx,
+                                                  float &dy, float &dz) {
+    rng_init_keyed(rng, pk, k);
     const float jx = rng_jitter(rng);  // :251
     const float jy = rng_jitter(rng);  // :252
     const uint32_t s = k / fr.quarter;
@@ -898,6 +899,10 @@ __device__ __forceinline__ void primary_ray(const FrameDev &fr, uint32_t p, uint
     float rz = (fr.m[2] * gx + fr.m[5] * gy) + (fr.m[8] * gz + 0.0f);
     normalize3(rx, ry, rz);
     dx = rx, dy = ry, dz = rz;
+}
+__device__ __forceinline__ void primary_ray(const FrameDev &fr, uint32_t p, uint32_t k, Rng &rng, float &dx,
+                                            float &dy, float &dz) {
+    primary_ray_keyed(fr, p, rng_pixel_key(fr.seed, p), k, rng, dx, dy, dz);
 }
 
 // local pixel index (rank-local packed rows) -> global pixel index
@@ -1480,30 +1485,45 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
     if (wk.pixel_major && (wk.samples & 63u) == 0) {
         // a wave's 64 path ids are 64 samples of ONE pixel: slot, pixel and cursor are wave-uniform — one division and one
         // scalar fetch each per wave instead of per lane (round 3: 3.2 -> 2.9 ms for the 530.8 M rays of the bench frame)
+        // Round 4: a wave takes a whole PIXEL — all its samples, 64 at a time — so that the two dependent scalar fetches
+        // (active[slot], then the pixel's cursor) and the pixel half of the stream key are paid once per pixel, not once
+        // per 64 samples: the kernel was waiting on those fetches for 58 % of its wave cycles (3.2 -> 2.x ms)
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-        for (uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-             w * 64u < total; w += waves) {
-            const uint32_t pid0 = w * 64u, s_idx = pid0 / wk.samples, j = pid0 - s_idx * wk.samples + lane;
-            bool live = false;
+        const uint32_t chunks = wk.samples >> 6;
+        for (uint32_t s_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+             s_idx < wk.n_pad; s_idx += waves) {
+            const uint32_t pid_base = s_idx * wk.samples;
             if (s_idx < wk.n_active) {
                 const uint32_t lp = wk.active[s_idx];
-                const uint32_t k = sample_index(fr, px, lp, j);
-                float dx = 0.f, dy = 0.f, dz = 0.f;
-                uint32_t depth = 0xFFFFFFFFu;
-                if (k < fr.kmax) {
-                    Rng rng;
-                    primary_ray(fr, global_pixel(fr, lp), k, rng, dx, dy, dz);
-                    if (LIVE) live = !step_is_dead<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
-                    else depth = fr.camera_bits ? step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f) : 0u;
+                const uint32_t pixel = global_pixel(fr, lp);
+                const PixelKey pk = rng_pixel_key(fr.seed, pixel);
+                const uint32_t cur = px.cursor[lp];  // (sample_index, with the cursor fetched once)
+                const uint32_t k0 = cur & ~kCursorStrided, kstep = (cur & kCursorStrided) ? fr.quarter : 1u;
+                for (uint32_t ch = 0; ch < chunks; ++ch) {
+                    const uint32_t j = ch * 64u + lane;
+                    const uint32_t k = (fr.lead != 0 && j >= fr.lead) ? (j - fr.lead + 1u) * fr.quarter : k0 + j * kstep;
+                    bool live = false;
+                    float dx = 0.f, dy = 0.f, dz = 0.f;
+                    uint32_t depth = 0xFFFFFFFFu;
+                    if (k < fr.kmax) {
+                        Rng rng;
+                        primary_ray_keyed(fr, pixel, pk, k, rng, dx, dy, dz);
+                        if (LIVE) live = !step_is_dead<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+                        else depth = fr.camera_bits ? step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f) : 0u;
+                    }
+                    if (!LIVE) ((float4 *)pa.rayA)[pid_base + j] = make_float4(dx, dy, dz, __uint_as_float(depth));
+                    if (LIVE) {
+                        const unsigned long long bits = __builtin_amdgcn_ballot_w64(live);
+                        if (lane == 0) wk.live_mask[(pid_base >> 6) + ch] = bits, wk.live_cnt[(pid_base >> 6) + ch] = (uint32_t)__popcll(bits);
+                    }
                 }
-                if (!LIVE) ((float4 *)pa.rayA)[pid0 + lane] = make_float4(dx, dy, dz, __uint_as_float(depth));
-            } else if (!LIVE) {  // padding slots of the pass: marked like sample slots past a pixel's last sample
-                ((float4 *)pa.rayA)[pid0 + lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
-            }
-            if (LIVE) {
-                const unsigned long long bits = __builtin_amdgcn_ballot_w64(live);
-                if (lane == 0) wk.live_mask[w] = bits, wk.live_cnt[w] = (uint32_t)__popcll(bits);
+            } else {
+                // padding slots of the pass: marked like sample slots past a pixel's last sample
+                for (uint32_t ch = 0; ch < chunks; ++ch) {
+                    if (!LIVE) ((float4 *)pa.rayA)[pid_base + ch * 64u + lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+                    if (LIVE && lane == 0) wk.live_mask[(pid_base >> 6) + ch] = 0ull, wk.live_cnt[(pid_base >> 6) + ch] = 0u;
+                }
             }
         }
         return;
@@ -2116,7 +2136,8 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         const bool fin = (rflags >> 31) != 0;
         const bool material = slot >= 0;
         // ends by its draws (bit 0 / 1 by the material flag) and no light sphere in reach (bit 2): nothing to shade
-        const bool done = fin && (((material ? rflags : rflags >> 1) & 1u) != 0) && (rflags & 4u) == 0;
+        // (wk.keep_all: nothing is settled here — every ray gets its record and its full RayCast in k_shade)
+        const bool done = !wk.keep_all && fin && (((material ? rflags : rflags >> 1) & 1u) != 0) && (rflags & 4u) == 0;
         // (a bounce "ray" with a non-finite direction is traced like the others but is not counted as a ray: tally_add)
         const bool counted = SRC == 0 || finite3(dx, dy, dz);
         n_rays += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(done && counted));
