@@ -214,7 +214,7 @@ def main():
         esd_dt, esd_rays, esd_stats = timed(es_k, early_stop=True, pipeline=0)
 
     # The library's DEFAULT form of the same frame: whoever creates a ray also notes whether the Radiance step that traces
-    # it is the path's last one by the path's own draws; the traversal kernels settle such rays where they
+    # it is the path's last one by the path's own draws (DESIGN_HISTORY.md 5.1); the traversal kernels settle such rays where they
     # finish — BVH query, the light spheres' reach test, counted — and hand only the others to k_shade.  Bit-identical
     # frame in less time, but its settled rays are not full RayCasts, so it is a frame time, not the headline's ray rate.
     sorted_info = None

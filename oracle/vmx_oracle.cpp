@@ -497,7 +497,7 @@ struct MtRng {
     float jitter() { return df(eng); }
 };
 
-/* Audit of the argument behind the kernels' two-phase shading and VMX_SAMPLING_ELIDE_DEAD, made on the
+/* Audit of the argument behind the kernels' two-phase shading and VMX_SAMPLING_ELIDE_DEAD (DESIGN_HISTORY.md 5.1), made on the
  * oracle's own Radiance: before every step, from a COPY of the stream, predict "this is the path's last step whatever
  * it hits" per value of the material flag, and "no light sphere can colour it"; after the step, check what happened. */
 struct ElisionAudit {
@@ -879,7 +879,7 @@ void render_rows(const orc_scene &sc, const vmx_camera &cam, const vmx_opts &opt
  * optional normal perturbation by boundTextures[0] and albedo from boundTextures[1], and a
  * convergence break once more than 2 samples are in.
  *
- * Choices where the reference leaves behaviour open (stated in DESIGN.md §8 f-4 as well):
+ * Choices where the reference leaves behaviour open (stated in DESIGN_HISTORY.md §8 f-4 as well):
  *  - RNG.  The reference shares ONE std::mt19937 seeded with time(0) between all OpenMP threads
  *    without synchronisation (:30,65-66): not reproducible even run to run.  As for PathTracer, sample
  *    `s` of pixel `p` draws its two jitters from the keyed stream (seed, p, s).

@@ -56,7 +56,7 @@ void orc_raycast(const orc_scene *, const float *o, const float *d, uint32_t n, 
 void orc_radiance(const orc_scene *, const float *o, const float *d, uint32_t n,
                   const vmx_opts *opts, float *out4, vmx_stats *stats);
 /* Radiance with std::mt19937_64(seeds[i]) + uniform_real_distribution<double>, as the reference */
-/* audit of the elision / two-phase shading argument on the oracle's own Radiance: out6 = steps,
+/* audit of the elision / two-phase shading argument on the oracle's own Radiance (DESIGN_HISTORY.md 5.1): out6 = steps,
  * predicted_last, predicted_dead, and the three violation counts not_last, dead_changed, colour_mismatch (all must be 0) */
 void orc_audit_elision(const orc_scene *, const float *o, const float *d, uint32_t n, const vmx_opts *opts, float *out4,
                        uint64_t *out6);

@@ -287,7 +287,7 @@ def test_reference_rng_and_keyed_rng_agree_statistically():
 
 
 def test_elision_argument_holds_on_the_oracle():
-    """The argument behind the kernels' two-phase shading and VMX_SAMPLING_ELIDE_DEAD, audited on the
+    """The argument behind the kernels' two-phase shading and VMX_SAMPLING_ELIDE_DEAD (DESIGN_HISTORY.md 5.1), audited on the
     oracle's own Radiance, step by step: from a copy of the stream taken BEFORE a step, predict that the step is the
     path's last one for the material flag its hit turns out to have, and that no light sphere can colour it; then
     check that the path did end there (or went on with an all-NaN direction), that accumColour moved by exactly

@@ -2,7 +2,7 @@
 //
 // The camera-ray traversal kernel (k_trace_w<0>) fetches the node record of a wave-uniform step with one
 // s_load_dwordx16 and runs at ~0.6 of the VALU issue peak; an assembly loop with a third fewer instructions
-// per step was not faster.  Is the scalar cache the floor?  Dependent chains of record fetches
+// per step was not faster (DESIGN_HISTORY.md §9).  Is the scalar cache the floor?  Dependent chains of record fetches
 // (next index = a dword of the record just fetched), 8 waves per SIMD on every CU, with
 //   v0  s_load_dwordx16 only (latency / request rate of the scalar cache)
 //   v1  s_load_dwordx16 + the 16 VALU of the two slab tests taken straight from SGPRs (what a step must do)

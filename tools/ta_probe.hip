@@ -1,7 +1,7 @@
 // ta_probe.hip — what does a scattered 64-byte record gather cost on gfx950's vector-memory pipe?
 //
 // The bounce-ray traversal kernel (k_trace_w<1>) reads one 64-byte node record per lane and step as
-// four 16-byte loads and sits at the texture pipe.  Two cost models fit round 1's
+// four 16-byte loads and sits at the texture pipe (DESIGN_HISTORY.md §5).  Two cost models fit round 1's
 // counters equally well:
 //   A  a wave-level dwordx4 load costs a fixed ~16 pipe cycles whatever lanes are active
 //      -> only fewer wave-steps (higher lane occupancy) help

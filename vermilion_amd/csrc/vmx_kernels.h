@@ -74,7 +74,7 @@ struct WorkDev {
     unsigned int *live_cnt;
     const unsigned int *live_ids;
     const unsigned int *live_count;  // device scalar: entries of live_ids
-    // classified output of k_trace_w<.., SORT>: 32-byte records of the rays that still need shading,
+    // classified output of k_trace_w<.., SORT> (DESIGN_HISTORY.md 5.1): 32-byte records of the rays that still need shading,
     // the number of list entries reserved so far (device scalar, multiple of 256), the frame's counters
     void *out_rec;
     unsigned int *out_count;

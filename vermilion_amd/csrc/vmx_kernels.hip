@@ -11,7 +11,7 @@
 //   k_raygen       camera rays of a pass, each with the step_bits of its first Radiance step (pathtracer.cpp:251-280);
 //                  <1> + k_raygen_live: only the live ones (VMX_SAMPLING_ELIDE_DEAD, with path_compact.hip)
 //   k_trace_w      persistent BVH traversal of camera / bounce rays (bvh.cpp:47-145); <.., SORT>: settles the finished rays
-//                  whose step ends by its draws, hands the others on as records; k_trace_q: counting form
+//                  whose step ends by its draws, hands the others on as records (DESIGN_HISTORY.md 5.1); k_trace_q: counting form
 //   k_shade        RayCast tail + one Radiance step, id compaction  (meshEngine.cpp:365-508, pathtracer.cpp:36-196);
 //                  k_shade_ends: the two-phase form's first phase
 //   k_paths        traversal + shading fused, paths kept to their end (small passes, the tail of a pass)
@@ -67,7 +67,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------
-// RNG: xoshiro256** keyed by (seed, pixel, sample)  — DESIGN.md "RNG"
+// RNG: xoshiro256** keyed by (seed, pixel, sample)  — DESIGN.md §3
 // ---------------------------------------------------------------------------
 struct Rng {
     uint64_t s0, s1, s2, s3;
@@ -771,7 +771,7 @@ __device__ __forceinline__ bool path_shade_end(Path &P, const CastResult &c, Ste
 // nothing nearer yet (limit = infinity).  Then accumColour after the step equals accumColour before it bit for bit
 // (x + t * 0 == x for finite t), so the ray need not be traced: with the reference's r2 = 10 U that is 78 % of all rays.
 // (Under VMX_SAMPLING_CORRECTED r2 = U never exceeds 1: only Russian roulette, past depth 5, ever ends a path by its draws.)
-// The same facts as three bits — what the kernels pass along with a ray, step_is_dead being "bits == 3":
+// The same facts as three bits — what the kernels pass along with a ray (DESIGN_HISTORY.md 5.1), step_is_dead being "bits == 3":
 //   bit 0  the step is the path's last one if its hit has a material   (Russian roulette, or the draws of :98 / :156)
 //   bit 1  ... if its hit has none                                      (Russian roulette, or the draw of :170)
 //   bit 2  some light sphere passes sphereIntersect > 0 for the ray with nothing nearer yet: hitColour may be non-zero
@@ -1487,7 +1487,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
         // scalar fetch each per wave instead of per lane (round 3: 3.2 -> 2.9 ms for the 530.8 M rays of the bench frame)
         // Round 4: a wave takes a whole PIXEL — all its samples, 64 at a time — so that the two dependent scalar fetches
         // (active[slot], then the pixel's cursor) and the pixel half of the stream key are paid once per pixel, not once
-        // per 64 samples: the kernel was waiting on those fetches for 58 % of its wave cycles (3.2 -> 2.x ms)
+        // per 64 samples: the kernel was waiting on those fetches for 58 % of its wave cycles (3.2 -> 2.0 ms for the bench frame)
         const uint32_t lane = threadIdx.x & 63u;
         const uint32_t waves = gridDim.x * (blockDim.x >> 6);
         const uint32_t chunks = wk.samples >> 6;
@@ -2084,7 +2084,7 @@ __device__ __forceinline__ uint32_t uniform_descent(int &sp, uint32_t &cur, floa
 
 // LIVE (SRC 0, VMX_SAMPLING_ELIDE_DEAD): the work is the dense list of live camera paths — ray and hit record of list
 // entry i sit at rayA[i] / hit[i] — cut into 8 bands of whole waves (live_band)
-// SORT (classified output): instead of a hit record per ray, the finished rays of a wave are sorted on the
+// SORT (classified output, DESIGN_HISTORY.md 5.1): instead of a hit record per ray, the finished rays of a wave are sorted on the
 // spot when the wave refills.  A ray whose Radiance step is the path's last one by the path's own draws (the bits that
 // came with the ray) and that cannot meet a light sphere needs nothing more: it is counted here and forgotten.  The
 // others get a 32-byte record (direction, flag word | t, leaf slot, position) appended to a dense list — the wave
