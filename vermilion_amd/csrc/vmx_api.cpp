@@ -976,6 +976,10 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
                 // live bits -> ordered list of live path ids -> their rays, dense; trace and shade then work on the list
                 const uint32_t nwords = (uint32_t)(((uint64_t)n_pad * S + 63) / 64);
                 unsigned int *cnt = ws.live_u32.p, *offs = cnt + live_words_max, *len = offs + live_words_max;
+                // (one kernel for live bits, list and rays — a wave compacting its pixel's live samples through LDS and
+                // appending them to the list in chunks — was measured in round 4: the list then holds the pixels in the
+                // order the waves finish, the traversal kernel's 8 image bands lose their XCDs' L2 locality, and
+                // k_trace_w<0, LIVE> went 8.2 -> 15.9 ms (and the generation itself 4.2 -> 5.6 ms): the ORDERED list is worth its scan)
                 wk.live_mask = ws.live_mask.p, wk.live_cnt = cnt;
                 LAUNCH_TRY(launch_raygen(sc->dev, fr, wk, px, pa, s));
                 HIP_TRY((hipError_t)launch_live_compact(ws.live_mask.p, cnt, nwords, offs, ws.live_ids.p, len, ws.live_tmp.p, live_tmp_bytes, s));

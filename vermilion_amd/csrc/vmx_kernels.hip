@@ -776,9 +776,12 @@ __device__ __forceinline__ bool path_shade_end(Path &P, const CastResult &c, Ste
 //   bit 1  ... if its hit has none                                      (Russian roulette, or the draw of :170)
 //   bit 2  some light sphere passes sphereIntersect > 0 for the ray with nothing nearer yet: hitColour may be non-zero
 // (bits 0 and 1 are left clear for a path whose throughput is not finite: inf * 0 would be NaN, the step is shaded in full)
+// (test_lights == false: the caller has shown that no ray of this pixel can pass sphereIntersect > 0 for any emitting
+// sphere — pixel_may_reach_a_light — so bit 2 is clear without the per-ray tests, and the direction is not needed at all)
 template <bool TEX>
 __device__ __forceinline__ uint32_t step_bits(const SceneDev &sc, float r2scale, Rng rng, uint32_t depth, float ox, float oy,
-                                              float oz, float dx, float dy, float dz, float tr, float tg, float tb) {
+                                              float oz, float dx, float dy, float dz, float tr, float tg, float tb,
+                                              bool test_lights = true) {
     bool rr_end = false;
     if (depth + 1u > 5u) {
         const double rr = rng_u01(rng);
@@ -790,7 +793,7 @@ __device__ __forceinline__ uint32_t step_bits(const SceneDev &sc, float r2scale,
     bool ends_nomat = rr_end || (1.0 - (double)r2scale * b) < 0.0;
     if (TEX && !finite3(tr, tg, tb)) ends_mat = ends_nomat = false;
     bool light = false;
-    for (uint32_t i = 0; i < sc.emit_prefix; ++i) {
+    for (uint32_t i = 0; test_lights && i < sc.emit_prefix; ++i) {
         const SphereDev &q = sc.spheres[i];
         if (q.flags & 1u) {
             const float opx = q.cx - ox, opy = q.cy - oy, opz = q.cz - oz;
@@ -903,6 +906,43 @@ __device__ __forceinline__ void primary_ray_keyed(const FrameDev &fr, uint32_t p
 __device__ __forceinline__ void primary_ray(const FrameDev &fr, uint32_t p, uint32_t k, Rng &rng, float &dx,
                                             float &dy, float &dz) {
     primary_ray_keyed(fr, p, rng_pixel_key(fr.seed, p), k, rng, dx, dy, dz);
+}
+
+// Can ANY camera ray of pixel p pass sphereIntersect > 0 (meshEngine.cpp:182-194, nothing nearer yet) for some emitting
+// sphere?  A conservative answer for the whole pixel, so that k_raygen need not run the per-ray tests — nor, where the
+// step's draws already say "last step", form the ray's direction at all — for the pixels that cannot: most of a frame.
+// The sample directions of a pixel are normalize(M film) with the film point within half a pixel of the centre
+// ((px - 0.25) / W - 0.5, pathtracer.cpp:251-252 with the offsets' range [-0.75, 0.25)): a cone of half-angle phi,
+// sin phi <= half the pixel's film diagonal / |film point|, around the centre direction a.  For a sphere (centre c,
+// radius r), op = c - o, cos theta = op.a / |op|: every ray of the cone has op.d / |op| <= m = cos(theta - phi), and
+// sphereIntersect returns 0 when b^2 < |op|^2 - r^2 (negative discriminant) or when b < 0 with the origin outside the
+// sphere (both roots negative).  "Cannot reach" is claimed only with max(m, 0)^2 (1 + 1e-4) + 1e-3 < 1 - r^2 / |op|^2:
+// a margin five orders of magnitude above the float rounding of b = dot(op, d), |op|^2 and r^2 that the per-ray test
+// (sphere_in_reach) computes with — a sphere within ~1.8 degrees of the cone is simply tested per ray as before.
+__device__ __forceinline__ bool pixel_may_reach_a_light(const SceneDev &sc, const FrameDev &fr, uint32_t p) {
+    const float hx = ((float)(p % fr.width) - 0.25f) / (float)fr.width - 0.5f;
+    const float hy = ((float)(p / fr.width) - 0.25f) / (float)fr.height - 0.5f;
+    const float gx = hx * fr.sensor_x, gy = -(hy * fr.sensor_y), gz = -fr.film_dist;
+    const float ax = fr.m[0] * gx + fr.m[3] * gy + fr.m[6] * gz;
+    const float ay = fr.m[1] * gx + fr.m[4] * gy + fr.m[7] * gz;
+    const float az = fr.m[2] * gx + fr.m[5] * gy + fr.m[8] * gz;
+    const float alen = sqrtf(ax * ax + ay * ay + az * az);
+    const float px = fr.sensor_x / (float)fr.width, py = fr.sensor_y / (float)fr.height;
+    const float sphi = fminf(0.505f * sqrtf(px * px + py * py) / alen, 1.0f);  // half the diagonal, +1 %
+    const float cphi = sqrtf(fmaxf(1.0f - sphi * sphi, 0.0f));
+    bool may = !(alen > 0.0f);  // (a degenerate film: no claim)
+    for (uint32_t i = 0; i < sc.emit_prefix; ++i) {
+        const SphereDev &q = sc.spheres[i];
+        if (!(q.flags & 1u)) continue;
+        const float opx = q.cx - fr.px, opy = q.cy - fr.py, opz = q.cz - fr.pz;
+        const float C = opx * opx + opy * opy + opz * opz;
+        const float ct = (opx * ax + opy * ay + opz * az) / (sqrtf(C) * alen);
+        const float st = sqrtf(fmaxf(1.0f - ct * ct, 0.0f));
+        const float m = ct >= cphi ? 1.0f : fmaxf(ct * cphi + st * sphi, 0.0f);  // cos(theta - phi); 1 inside the cone
+        const float clear = 1.0f - q.rad2 / C;                                    // 1 - r^2 / |op|^2
+        if (!(m * m * 1.0001f + 1e-3f < clear)) may = true;                      // (NaN / inf / origin inside: may)
+    }
+    return may;
 }
 
 // local pixel index (rank-local packed rows) -> global pixel index
@@ -1498,6 +1538,8 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
                 const uint32_t lp = wk.active[s_idx];
                 const uint32_t pixel = global_pixel(fr, lp);
                 const PixelKey pk = rng_pixel_key(fr.seed, pixel);
+                // (the step bits are drawn at all only where a kernel reads them: fr.camera_bits / LIVE)
+                const bool lights = (LIVE || fr.camera_bits) && pixel_may_reach_a_light(sc, fr, pixel);
                 const uint32_t cur = px.cursor[lp];  // (sample_index, with the cursor fetched once)
                 const uint32_t k0 = cur & ~kCursorStrided, kstep = (cur & kCursorStrided) ? fr.quarter : 1u;
                 for (uint32_t ch = 0; ch < chunks; ++ch) {
@@ -1508,9 +1550,19 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
                     uint32_t depth = 0xFFFFFFFFu;
                     if (k < fr.kmax) {
                         Rng rng;
-                        primary_ray_keyed(fr, pixel, pk, k, rng, dx, dy, dz);
-                        if (LIVE) live = !step_is_dead<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
-                        else depth = fr.camera_bits ? step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f) : 0u;
+                        if (LIVE && !lights) {
+                            // no ray of this pixel can meet a light: whether the path is live is decided by its draws
+                            // alone — the stream keyed, the two jitter draws skipped, the step's three numbers drawn —
+                            // and the ray itself is formed later, for the live paths only (k_raygen_live)
+                            rng_init_keyed(rng, pk, k);
+                            (void)rng_next(rng);
+                            (void)rng_next(rng);
+                            live = step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, false) != 3u;
+                        } else {
+                            primary_ray_keyed(fr, pixel, pk, k, rng, dx, dy, dz);
+                            if (LIVE) live = !step_is_dead<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f);
+                            else depth = fr.camera_bits ? step_bits<false>(sc, fr.r2scale, rng, 0, fr.px, fr.py, fr.pz, dx, dy, dz, 1.f, 1.f, 1.f, lights) : 0u;
+                        }
                     }
                     if (!LIVE) ((float4 *)pa.rayA)[pid_base + j] = make_float4(dx, dy, dz, __uint_as_float(depth));
                     if (LIVE) {
