@@ -146,3 +146,81 @@ def test_division_by_the_image_size_with_a_reciprocal_and_one_fma_is_the_ieee_di
         assert fd.value == 0 and dd.value == 0, (n, fd.value, dd.value)
         total += 2 * 0x7F800000
     assert total > 1.7e10
+
+
+def test_pixel_light_cull_is_conservative():
+    """vmx_kernels.hip: pixel_may_reach_a_light — k_raygen's per-pixel answer to "can any camera ray of this pixel pass
+    sphereIntersect > 0 (meshEngine.cpp:182-194) for this emitting sphere?".  Where it says NO, no ray of the pixel may
+    reach the sphere: restated here in float32 as the kernel computes it and checked against the reference's own
+    arithmetic (the oracle's camera rays of many samples per pixel, plus the corners and edge midpoints of the sample
+    footprint) for random cameras and spheres placed all around the view, most of them right at the edge of it."""
+    import oracle_lib as O
+    import vermilion_amd as va
+    rng = np.random.default_rng(11)
+
+    def may_reach(cam_m, pos, film_dist, sensor, W, H, p, centre, rad2):
+        f = np.float32
+        hx = (f(p % W) - f(0.25)) / f(W) - f(0.5)
+        hy = (f(p // W) - f(0.25)) / f(H) - f(0.5)
+        gx, gy, gz = hx * f(sensor[0]), -(hy * f(sensor[1])), -f(film_dist)
+        a = (cam_m[:, 0] * gx + cam_m[:, 1] * gy + cam_m[:, 2] * gz).astype(f)     # columns of the 3x3 matrix
+        alen = np.sqrt(f(a @ a))
+        px_, py_ = f(sensor[0]) / f(W), f(sensor[1]) / f(H)
+        sphi = min(f(0.505) * np.sqrt(px_ * px_ + py_ * py_) / alen, f(1))
+        cphi = np.sqrt(max(f(1) - sphi * sphi, f(0)))
+        op = (np.float32(centre) - np.float32(pos)).astype(f)
+        C = f(op @ op)
+        ct = f(op @ a) / (np.sqrt(C) * alen)
+        st = np.sqrt(max(f(1) - ct * ct, f(0)))
+        m = f(1) if ct >= cphi else max(ct * cphi + st * sphi, f(0))
+        clear = f(1) - f(rad2) / C
+        return not (m * m * f(1.0001) + f(1e-3) < clear)
+
+    def reaches(o, d, centre, rad):  # sphereIntersect > 0, the reference's mixed float / double arithmetic
+        op = (np.float32(centre)[None, :] - o).astype(np.float32)
+        B, C = dot3(op, d).astype(np.float64), dot3(op, op).astype(np.float64)
+        det = B * B - C + np.float64(f32(f32(rad) * f32(rad)))
+        with np.errstate(invalid="ignore"):
+            s = np.sqrt(det)
+        return (det >= 0) & ((B - s > 1e-4) | (B + s > 1e-4))
+
+    culled = violations = tested = 0
+    for trial in range(60):
+        W, H = int(rng.choice([33, 64, 160])), int(rng.choice([17, 40, 90]))
+        pos = rng.uniform(-1500, 1500, 3)
+        rot = rng.uniform(-180, 180, 3) * np.array([0.4, 1.0, 0.2])
+        cam = va.make_camera(pos, rot, W, H, 64, back_size=(3.6, 3.6 * H / W))
+        M = O.camera_matrix(cam).T  # [row][col] -> columns M[:, c]
+        rays = [O.primary_rays(cam, va.make_opts(seed=trial), k) for k in (0, 9, 17, 25, 33, 41, 50, 63)]
+        # spheres aimed at random pixels' directions, at an angular offset around the edge of what the pixel sees
+        o0, d0 = rays[0]
+        for _ in range(12):
+            p = int(rng.integers(0, W * H))
+            dist = np.exp(rng.uniform(np.log(5), np.log(5000)))
+            rad = dist * np.exp(rng.uniform(np.log(1e-3), np.log(0.5)))
+            axis = d0[p].astype(np.float64)
+            t = np.cross(axis, rng.normal(size=3))
+            t /= np.linalg.norm(t)
+            ang = np.arcsin(min(rad / dist, 1.0)) + rng.uniform(-0.05, 0.08)   # tangent direction +- a few degrees
+            centre = pos + dist * (np.cos(ang) * axis + np.sin(ang) * t)
+            rad2 = f32(f32(rad) * f32(rad))
+            for q in {p, max(p - 1, 0), min(p + 1, W * H - 1), max(p - W, 0), min(p + W, W * H - 1)}:
+                tested += 1
+                if may_reach(np.float32(M), np.float32(pos), cam.back_distance, cam.back_size, W, H, q, centre, rad2):
+                    continue
+                culled += 1
+                for o, d in rays:
+                    if reaches(o[q:q + 1], d[q:q + 1], centre, rad)[0]:
+                        violations += 1
+                # the footprint's corners and edge midpoints (offsets [-0.75, 0.25] around the pixel coordinate, incl. the ends)
+                for ex in (-0.75, -0.25, 0.25):
+                    for ey in (-0.75, -0.25, 0.25):
+                        hx = (q % W + ex) / W - 0.5
+                        hy = (q // W + ey) / H - 0.5
+                        g = np.array([hx * cam.back_size[0], -hy * cam.back_size[1], -cam.back_distance])
+                        dd = M.astype(np.float64) @ g
+                        dd /= np.linalg.norm(dd)
+                        if reaches(np.float32(pos)[None, :], np.float32(dd)[None, :], centre, rad)[0]:
+                            violations += 1
+    assert violations == 0
+    assert culled > 0.2 * tested and culled < 0.95 * tested  # the test exercises both answers
