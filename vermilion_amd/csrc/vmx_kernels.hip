@@ -978,12 +978,17 @@ __device__ __forceinline__ void ray_load(const PathArrays &pa, uint32_t pid, Pat
     P.ox = a.x, P.oy = a.y, P.oz = a.z, P.dx = a.w;
     P.dy = b.x, P.dz = b.y, P.depth = __float_as_uint(b.z);
 }
-template <bool TEX>
+// RAD = false: accumColour is not fetched (k_shade<1> fetches and stores it only for the steps that change it)
+template <bool TEX, bool RAD = true>
 __device__ __forceinline__ void path_load_arrays(const PathArrays &pa, uint32_t pid, Path &P) {
     ray_load(pa, pid, P);
     rng_load(pa, pid, P.rng);
-    const float4 acc = ((const float4 *)pa.rad)[pid];
-    P.ar = acc.x, P.ag = acc.y, P.ab = acc.z, P.aw = acc.w;
+    if (RAD) {
+        const float4 acc = ((const float4 *)pa.rad)[pid];
+        P.ar = acc.x, P.ag = acc.y, P.ab = acc.z, P.aw = acc.w;
+    } else {
+        P.ar = P.ag = P.ab = P.aw = 0.f;
+    }
     if (TEX) {
         const float4 th = ((const float4 *)pa.thr)[pid];
         P.tr = th.x, P.tg = th.y, P.tb = th.z, P.tw = th.w;
@@ -2708,7 +2713,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             }
             if (run) {
                 if (FROMQ != 2) pid = wk.qids.ids[(size_t)sub * wk.qids.sub_capacity + pos];
-                path_load_arrays<TEX>(pa, pid, P);
+                path_load_arrays<TEX, false>(pa, pid, P);  // (accumColour: below, only where the step changes it)
             }
         }
         StepFlags fl = {false, false, false};
@@ -2723,8 +2728,21 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             const float2 h = FROMQ == 2 ? hrec : hits[SRC == 0 ? src : pid];
             cast_finish<true, SRC == 0>(sc, P.ox, P.oy, P.oz, P.dx, P.dy, P.dz, h.x, __float_as_int(h.y), c, s_geom,
                                         s_cam_op);
+            // A bounce step changes accumColour only by += accumRadiance * hitColour (pathtracer.cpp:43) — nothing when no
+            // light coloured the hit (x + t * 0 == x for finite t; the sums are never -0) — and, at depth 0 (explicit rays
+            // of vmx_radiance), by its fourth component (:44-47).  Six steps in seven change nothing: their path's
+            // 16 bytes of a 64-byte line are neither fetched nor written back (a third of this kernel's HBM traffic).
+            bool touch = SRC == 0;
+            if (SRC != 0) {
+                touch = P.depth == 0 || c.cr != 0.f || c.cg != 0.f || c.cb != 0.f;
+                if (TEX) touch = touch || !(finite3(P.tr, P.tg, P.tb) && fabsf(P.tw) < kInf);
+                if (touch) {
+                    const float4 acc = rad[pid];
+                    P.ar = acc.x, P.ag = acc.y, P.ab = acc.z, P.aw = acc.w;
+                }
+            }
             st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
-            if (SRC != 0 || !pa.rad_mask) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
+            if (SRC != 0 ? touch : !pa.rad_mask) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
         }
         bool alive = st == kPathNextRay;
         // (gathering the block's ~10 % of angles in LDS to evaluate cos/sin in full waves was measured:
