@@ -978,13 +978,29 @@ __device__ __forceinline__ void ray_load(const PathArrays &pa, uint32_t pid, Pat
     P.ox = a.x, P.oy = a.y, P.oz = a.z, P.dx = a.w;
     P.dy = b.x, P.dz = b.y, P.depth = __float_as_uint(b.z);
 }
+// accumColour of a path in the split passes (PathArrays::rad / rad_mask).  The mask bit of a path says "rad[pid] holds a
+// non-zero colour": a path that is black so far has neither a stored radiance nor a bit — k_resolve adds an exact +0 for
+// it — and the first step that colours it stores the sum and sets the bit (rare: one atomic).  Without a mask (fused
+// passes, vmx_radiance) every path's radiance is in rad.
+__device__ __forceinline__ bool rad_has(const PathArrays &pa, uint32_t pid) {
+    return !pa.rad_mask || ((pa.rad_mask[pid >> 6] >> (pid & 63u)) & 1ull) != 0;
+}
+__device__ __forceinline__ float4 rad_fetch(const PathArrays &pa, uint32_t pid, bool has) {
+    return has ? ((const float4 *)pa.rad)[pid] : make_float4(0.f, 0.f, 0.f, -100.f);
+}
+__device__ __forceinline__ void rad_commit(const PathArrays &pa, uint32_t pid, float4 v, bool had) {
+    if (had || v.x != 0.f || v.y != 0.f || v.z != 0.f) {  // (NaN != 0: a NaN colour is stored)
+        ((float4 *)pa.rad)[pid] = v;
+        if (!had) atomicOr(&pa.rad_mask[pid >> 6], 1ull << (pid & 63u));
+    }
+}
 // RAD = false: accumColour is not fetched (k_shade<1> fetches and stores it only for the steps that change it)
 template <bool TEX, bool RAD = true>
 __device__ __forceinline__ void path_load_arrays(const PathArrays &pa, uint32_t pid, Path &P) {
     ray_load(pa, pid, P);
     rng_load(pa, pid, P.rng);
     if (RAD) {
-        const float4 acc = ((const float4 *)pa.rad)[pid];
+        const float4 acc = rad_fetch(pa, pid, rad_has(pa, pid));
         P.ar = acc.x, P.ag = acc.y, P.ab = acc.z, P.aw = acc.w;
     } else {
         P.ar = P.ag = P.ab = P.aw = 0.f;
@@ -1292,7 +1308,9 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, float4 *__restri
                     fl.was_ray = is_ray;
                     alive = path_shade<TEX, true>(sc, SampCfg{fr.r2scale, fr.libm_double, fr.elide_dead}, P, c, fl, s_geom);
                     if (!alive) {
-                        rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
+                        // (tail of a split pass: the path's bit says whether it had a stored colour; fused passes: no mask)
+                        if (SRC == 2) rad_commit(pa, P.dest, make_float4(P.ar, P.ag, P.ab, P.aw), rad_has(pa, P.dest));
+                        else rad[P.dest] = make_float4(P.ar, P.ag, P.ab, P.aw);
                         has = false;
                     }
                 }
@@ -2202,18 +2220,6 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
         const bool todo = fin && !done;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(todo);
         const uint32_t n = (uint32_t)__popcll(m);
-        if (SRC == 0 && !LIVE) {
-            // the radiance mask (PathArrays::rad_mask, cleared for the pass): k_shade stores the radiance of every ray handed
-            // on, so their bits can be set here — as one word where the wave holds the 64 paths of one (camera waves refill
-            // all their lanes at once, with consecutive path ids), instead of one atomic per path in k_shade (4.6 -> 5.1 ms)
-            const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pid);
-            const bool whole = (p0 & 63u) == 0u && __builtin_amdgcn_ballot_w64(fin && pid == p0 + lane) == ~0ull;
-            if (whole) {
-                if (lane == 0) pa.rad_mask[p0 >> 6] = m;
-            } else if (todo) {
-                atomicOr(&pa.rad_mask[pid >> 6], 1ull << (pid & 63u));
-            }
-        }
         float4 *__restrict__ rec = (float4 *)wk.out_rec;
         if (n != 0) {
             constexpr uint32_t kRec = SRC == 0 ? 2 : 1;  // float4s per entry; the last one holds (t, leaf slot, position, -)
@@ -2732,17 +2738,22 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             // light coloured the hit (x + t * 0 == x for finite t; the sums are never -0) — and, at depth 0 (explicit rays
             // of vmx_radiance), by its fourth component (:44-47).  Six steps in seven change nothing: their path's
             // 16 bytes of a 64-byte line are neither fetched nor written back (a third of this kernel's HBM traffic).
-            bool touch = SRC == 0;
+            bool touch = SRC == 0, had = true;
             if (SRC != 0) {
                 touch = P.depth == 0 || c.cr != 0.f || c.cg != 0.f || c.cb != 0.f;
                 if (TEX) touch = touch || !(finite3(P.tr, P.tg, P.tb) && fabsf(P.tw) < kInf);
                 if (touch) {
-                    const float4 acc = rad[pid];
+                    had = rad_has(pa, pid);
+                    const float4 acc = rad_fetch(pa, pid, had);
                     P.ar = acc.x, P.ag = acc.y, P.ab = acc.z, P.aw = acc.w;
                 }
             }
             st = path_shade_begin<TEX>(sc, fr.r2scale, P, c, fl, mid);
-            if (SRC != 0 ? touch : !pa.rad_mask) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
+            if (SRC != 0) {
+                if (touch) rad_commit(pa, pid, make_float4(P.ar, P.ag, P.ab, P.aw), had);
+            } else if (!pa.rad_mask) {
+                rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
+            }
         }
         bool alive = st == kPathNextRay;
         // (gathering the block's ~10 % of angles in LDS to evaluate cos/sin in full waves was measured:
@@ -2766,12 +2777,10 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             // camera paths: most end at their first hit with accumColour.rgb == 0 (no light sphere hit): nothing to store
             // for them, k_resolve adds +0 (x + 0 == x bit for bit; the sums are never -0).  A wave's 64 paths are one
             // aligned word of the mask (path ids of an item are consecutive, 256 per block)
-            // (FROMQ 2 without a live list: the traversal kernel has set the mask bit of every ray it handed on)
-            const bool preset = FROMQ == 2 && !listed;
-            const bool need = run && (preset || alive || P.ar != 0.f || P.ag != 0.f || P.ab != 0.f);
+            // (a path that goes on black stores nothing either: the step that colours it later sets its bit, rad_commit)
+            const bool need = run && (P.ar != 0.f || P.ag != 0.f || P.ab != 0.f);
             if (need) rad[pid] = make_float4(P.ar, P.ag, P.ab, P.aw);
-            if (preset) {
-            } else if (listed || FROMQ != 0) {  // the mask was cleared for the pass / written by k_shade_ends; neighbours share words
+            if (listed || FROMQ != 0) {  // the mask was cleared for the pass / written by k_shade_ends; neighbours share words
                 if (need) atomicOr(&pa.rad_mask[pid >> 6], 1ull << (pid & 63u));
             } else {
                 const unsigned long long word = __builtin_amdgcn_ballot_w64(need);
@@ -2910,10 +2919,11 @@ k_shade_ends(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa, unsigned long 
                 if ((threadIdx.x & 63u) == 0 && src < wk.samples * wk.n_pad) pa.rad_mask[src >> 6] = word;
             }
         } else if (lit) {
-            float4 acc = rad[pid];
+            const bool had = rad_has(pa, pid);
+            float4 acc = rad_fetch(pa, pid, had);
             if (TEX) acc.x = acc.x + tr * cr, acc.y = acc.y + tg * cg, acc.z = acc.z + tb * cb;
             else acc.x = acc.x + cr, acc.y = acc.y + cg, acc.z = acc.z + cb;
-            rad[pid] = acc;
+            rad_commit(pa, pid, acc, had);
         }
         StepFlags fl = {false, false, false};
         fl.was_ray = depth == 0u ? true : finite3(dx, dy, dz);
