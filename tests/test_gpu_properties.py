@@ -238,6 +238,27 @@ def test_config5_stripes_of_the_4k_1024spp_frame(sponza):
         assert sp["samples"] == part.shape[0] * W * spp
 
 
+def test_config5_rank_against_the_oracle(sponza):
+    """BASELINE config 5 (3840x2160, 1024 spp, sharded): what one rank of 128 renders — 4-row stripes spread over the
+    whole image height, 66.8 M samples — against the oracle's same rows (pathtracer.cpp:200-328 restated), bit for bit,
+    fixed count and early stop, default and headline form, with the ray / sample counters"""
+    W, H, spp = 3840, 2160, 1024
+    cam = sponza_cam(W, H, spp)
+    osc = O.OracleScene(*scenes.sponza260k())
+    sub = dict(rank=37, world=128, stripe_rows=4)
+    rows = va.local_row_indices(H, 4, 37, 128)
+    ref, ost = osc.render(cam, va.make_opts(seed=8, early_stop=False, **sub))
+    assert ref.shape == (len(rows), W, 5) and ost["samples"] == len(rows) * W * spp
+    for kw in (dict(), dict(pipeline=0x100), dict(sampling=va.VMX_SAMPLING_PARITY | va.VMX_SAMPLING_ELIDE_DEAD)):
+        part, sp = sponza.render(cam, va.make_opts(seed=8, early_stop=False, **sub, **kw))
+        assert np.array_equal(bits(part), bits(ref)), kw
+        if "sampling" not in kw:
+            assert sp["rays_primary"] == ost["rays_primary"] and sp["rays_secondary"] == ost["rays_secondary"], kw
+    eref, eost = osc.render(cam, va.make_opts(seed=8, early_stop=True, **sub))
+    epart, esp = sponza.render(cam, va.make_opts(seed=8, early_stop=True, **sub))
+    assert np.array_equal(bits(epart), bits(eref)) and esp["samples"] == eost["samples"]
+
+
 def test_per_kernel_timings_of_the_last_render(sponza):
     """vmx_scene_timings: what bench.py's roofline object takes its launch durations from"""
     cam = sponza_cam(480, 270, 64)
