@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: the mirror of the reference's plugin
 surface, the synthetic scenes and the stripe sharding."""
+import os
+
 import numpy as np
 import pytest
 
@@ -95,3 +97,20 @@ def test_make_opts_and_spheres():
     arr = va.spheres_array([dict(centre=(1, 2, 3), radius=4, colour=(5, 6, 7), emit=True, normal_sign=-1)])
     assert list(arr[0].centre) == [1, 2, 3] and arr[0].flags == 1 and arr[0].normal_sign == -1
     assert list(arr[0].normal_centre) == [1, 2, 3]
+
+
+def test_fastdiv_equals_integer_division(tmp_path):
+    """vmx_device.h: FastDiv (multiply-high + two shifts instead of a ~25-instruction division by the samples per pixel /
+    the image width in the kernels) is exact for every 32-bit numerator: awkward and random divisors, numerators around
+    every multiple boundary and across the range"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        import pytest
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fastdiv_test"
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "vermilion_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "fastdiv_test.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "mismatches 0" in out.stdout, out.stdout

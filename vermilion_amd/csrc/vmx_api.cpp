@@ -249,6 +249,7 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
     fr.sensor_x = cam.back_size[0], fr.sensor_y = cam.back_size[1];
     fr.width = W, fr.height = H;
     fr.inv_width = 1.0 / (double)W, fr.inv_height = 1.0 / (double)H;
+    fr.div_width = make_fastdiv(W);
     fr.spp = spp, fr.quarter = spp / 4, fr.kmax = 4 * (spp / 4);
     fr.nmin = (uint32_t)std::floor(std::sqrt((double)spp));
     fr.early_stop = o.early_stop ? 1u : 0u;
@@ -259,6 +260,7 @@ int make_frame(const vmx_camera &cam, const vmx_opts &o, FrameDev &fr) {
     fr.world = o.world <= 1 ? 1u : o.world;
     fr.rank = o.world <= 1 ? 0u : o.rank;
     fr.stripe_rows = o.stripe_rows ? o.stripe_rows : 16u;
+    fr.div_stripe = make_fastdiv(fr.stripe_rows);
     if (fr.rank >= fr.world) return fail(VMX_ERR_INVALID, "rank must be < world");
     fr.local_rows = local_rows_of(H, fr.stripe_rows, fr.rank, fr.world);
     fr.seed = o.seed;
@@ -959,7 +961,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.nsrc = 8;
             wk.refill_min = tn.refill_primary, wk.shade_min = tn.shade_min;
             wk.active = ws.active[cur_list].p;
-            wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S;
+            wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S, wk.div_samples = make_fastdiv(S);
             wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;
             wk.band_items = wk.band_slots * S;
             wk.pixel_major = 1;
@@ -1022,7 +1024,7 @@ int render_impl(vmx_scene *sc, const vmx_camera *cam, const vmx_opts *opts, floa
             wk.nsrc = 8;
             wk.refill_min = tn.refill_min, wk.shade_min = tn.shade_min;
             wk.active = ws.active[cur_list].p;
-            wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S;
+            wk.n_active = n_active, wk.n_pad = n_pad, wk.samples = S, wk.div_samples = make_fastdiv(S);
             wk.band_slots = (((n_pad + 7u) / 8u) + 63u) & ~63u;
             wk.band_items = wk.band_slots * S;
             wk.pixel_major = 1;

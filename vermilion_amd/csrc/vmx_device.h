@@ -89,6 +89,25 @@ struct DevCounters {
     unsigned long long samples, discarded, pixels_done, overflow;
 };
 
+// Division of a 32-bit index by a launch constant (samples per pixel of a pass, image width, rows per stripe) as a
+// multiply-high and two shifts (Granlund-Montgomery, the branch-free form): exact for every 32-bit numerator.  A plain
+// n / d with a run-time d is ~25 VALU instructions, and k_shade<0> did three per camera path.
+//   l = ceil(log2 d)   m = floor(2^32 (2^l - d) / d) + 1   q = (t + ((n - t) >> min(l, 1))) >> max(l - 1, 0),  t = mulhi(m, n)
+struct FastDiv {
+    uint32_t m, sh1, sh2, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    if (d == 0) d = 1;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDiv f;
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
+    f.sh1 = l < 1 ? l : 1u;
+    f.sh2 = l > 0 ? l - 1 : 0u;
+    f.d = d;
+    return f;
+}
+
 // Camera/frame constants for ray generation (pathtracer.cpp:216-221, 251-280)
 struct FrameDev {
     float m[9];  // column-major 3x3 camera matrix
@@ -111,6 +130,7 @@ struct FrameDev {
     uint32_t stripe_rows, rank, world;
     uint64_t seed;
     double inv_width, inv_height;  // RN(1 / width), RN(1 / height) by IEEE division on the host (div_by_count)
+    FastDiv div_width, div_stripe;  // index / width, row / stripe_rows (global_pixel)
 };
 
 // Path state across a bounce boundary: 6 planes of 16 bytes, plane p of slot s

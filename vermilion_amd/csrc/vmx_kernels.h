@@ -61,6 +61,7 @@ struct WorkDev {
     // primary source
     const unsigned int *active;
     uint32_t n_active, n_pad, samples;
+    FastDiv div_samples;        // path id / samples (pixel-major ids); make_fastdiv(samples), set with samples
     uint32_t band_slots;        // slots per band (multiple of 64)
     uint32_t band_items;        // band_slots * samples
     uint32_t pixel_major;       // 1: pid = slot * samples + j (samples of a pixel contiguous); 0: j * n_pad + slot

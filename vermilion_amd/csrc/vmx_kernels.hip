@@ -945,11 +945,16 @@ __device__ __forceinline__ bool pixel_may_reach_a_light(const SceneDev &sc, cons
     return may;
 }
 
+// n / d for a launch constant d (vmx_device.h: FastDiv)
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f) {
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
 // local pixel index (rank-local packed rows) -> global pixel index
 __device__ __forceinline__ uint32_t global_pixel(const FrameDev &fr, uint32_t lp) {
-    const uint32_t lrow = lp / fr.width, x = lp - lrow * fr.width;
     if (fr.world <= 1) return lp;
-    const uint32_t ls = lrow / fr.stripe_rows, r = lrow - ls * fr.stripe_rows;
+    const uint32_t lrow = fast_div(lp, fr.div_width), x = lp - lrow * fr.width;
+    const uint32_t ls = fast_div(lrow, fr.div_stripe), r = lrow - ls * fr.stripe_rows;
     const uint32_t grow = (ls * fr.world + fr.rank) * fr.stripe_rows + r;
     return grow * fr.width + x;
 }
@@ -1352,7 +1357,7 @@ k_paths(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, float4 *__restri
                         if (SRC == 0) {
                             uint32_t j, s_idx;
                             if (wk.pixel_major) {
-                                const uint32_t sl = item / wk.samples;
+                                const uint32_t sl = fast_div(item, wk.div_samples);
                                 j = item - sl * wk.samples, s_idx = src * wk.band_slots + sl;
                             } else {
                                 j = item / wk.band_slots, s_idx = src * wk.band_slots + (item - j * wk.band_slots);
@@ -1606,7 +1611,7 @@ k_raygen(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa) 
     // (n_pad, and with it total, is a multiple of 64: a wave's 64 lanes hold 64 consecutive path ids and run the body together)
     for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < total; pid += gridDim.x * blockDim.x) {
         uint32_t j, s_idx;
-        if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
+        if (wk.pixel_major) s_idx = fast_div(pid, wk.div_samples), j = pid - s_idx * wk.samples;
         else j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
         uint32_t pid2, pixel, k;
         float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -1635,7 +1640,7 @@ k_raygen_live(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t pid = wk.live_ids[i];
         uint32_t j, s_idx;
-        if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
+        if (wk.pixel_major) s_idx = fast_div(pid, wk.div_samples), j = pid - s_idx * wk.samples;
         else j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
         uint32_t pid2, pixel, k;
         float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -1727,7 +1732,7 @@ k_trace_q(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa,
                         // band-local item -> path id; the ray was written by k_raygen
                         uint32_t j, s_idx;
                         if (wk.pixel_major) {
-                            const uint32_t sl = item / wk.samples;
+                            const uint32_t sl = fast_div(item, wk.div_samples);
                             j = item - sl * wk.samples, s_idx = src * band_slots + sl;
                         } else {
                             j = item / band_slots, s_idx = src * band_slots + (item - j * band_slots);
@@ -2489,7 +2494,7 @@ k_trace_w(SceneDev sc, FrameDev fr, WorkDev wk, PathArrays pa) {
                     } else if (SRC == 0) {
                         uint32_t j, s_idx;
                         if (wk.pixel_major) {
-                            const uint32_t sl = item / wk.samples;
+                            const uint32_t sl = fast_div(item, wk.div_samples);
                             j = item - sl * wk.samples, s_idx = src * band_slots + sl;
                         } else {
                             j = item / band_slots, s_idx = src * band_slots + (item - j * band_slots);
@@ -2677,7 +2682,7 @@ k_shade(SceneDev sc, FrameDev fr, WorkDev wk, PixelStateDev px, PathArrays pa, I
             }
             if (listed) pid = src < live_n ? wk.live_ids[src] : 0xFFFFFFFFu;  // (no such path: j >= samples below)
             uint32_t j, s_idx;
-            if (wk.pixel_major) s_idx = pid / wk.samples, j = pid - s_idx * wk.samples;
+            if (wk.pixel_major) s_idx = fast_div(pid, wk.div_samples), j = pid - s_idx * wk.samples;
             else j = pid / wk.n_pad, s_idx = pid - j * wk.n_pad;
             uint32_t pixel = 0, k = 0, pid2;
             run = j < wk.samples && s_idx < wk.n_pad && primary_item(fr, wk, px, j, s_idx, pid2, pixel, k);
