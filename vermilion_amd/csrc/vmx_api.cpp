@@ -408,8 +408,11 @@ constexpr uint32_t kPathsBlock = 256;
 int bind_stack(vmx_scene *sc, const Tuning &tn, uint32_t entries, uint32_t grid, uint64_t items, WorkDev &wk) {
     // items a wave reserves from its work source per atomic: 256 when every lane will take >= 256 of them, else 128
     // (measured: early-stop frame 15.6 -> 14.3 ms with 128, whole 256-spp frame unchanged; 64 costs the camera-ray
-    // kernel of the big frame 2 ms)
-    wk.reserve = items / ((uint64_t)grid * kPathsBlock) >= 256 ? 256u : 128u;
+    // kernel of the big frame 2 ms), 64 for launches of fewer than 64 items per lane: what a wave still holds privately
+    // when the list runs empty is part of the launch's drain (round 4, tools/shard_kernels.py: the first bounce
+    // generation of one rank of 8 — 9 M rays — 5.09 -> 4.94 ms; nothing measurable on larger launches)
+    const uint64_t per_lane = items / ((uint64_t)grid * kPathsBlock);
+    wk.reserve = per_lane >= 256 ? 256u : (per_lane >= 64 ? 128u : 64u);
     wk.lds_entries = entries;
     wk.leaf_min = tn.leaf_min;
     // + 1: k_trace_w keeps its bottom entry in LDS level 0
